@@ -1,0 +1,127 @@
+/* C ABI of libscmomer_hip.so: gfx950 (MI355X) kernels for the scMomer Performer RNA-encoder path.
+ *
+ * The reference (nobody927/scMomer) is pure Python/PyTorch and has no FFI of its own; each entry
+ * point below replaces the aten-op group of the cited reference lines.  A binding only needs
+ * device pointers, sizes and a stream (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; buffers are caller-owned, nothing
+ *     is allocated or freed by the library, and nothing synchronises the device;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - activations fed to matrix products are bf16 (raw uint16 storage); the residual stream,
+ *     statistics, gradients of parameters and all accumulations are f32;
+ *   - every function returns 0 on success, a negative SCM_E* code on a rejected argument, or a
+ *     positive hipError_t from the launch; scm_last_error() gives the text (host, thread-local);
+ *   - T = B*N tokens, D = model dim (<= 256, multiple of 8), head dim is 64 and the number of
+ *     random features is 266 (compile-time constants of the path).
+ */
+#ifndef SCMOMER_HIP_H
+#define SCMOMER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCM_EINVAL (-1)
+#define SCM_NB_FEATURES 266
+#define SCM_NB_FEATURES_PAD 288
+#define SCM_DIM_HEAD 64
+
+/* bf16 tensor view [B,H,N,64]: element (b,h,n,d) at p + b*sb + h*sh + n*sn + d (strides in elements,
+ * d contiguous, sb/sh/sn multiples of 8).  Covers both the reference's 'b h n d' layout
+ * (performer_pytorch.py:376) and head slices of a fused [B*N, 3*H*64] projection buffer. */
+typedef struct { void* p; int64_t sb, sh, sn; } scm_view4;
+
+int scm_version(void);
+const char* scm_last_error(void); /* host */
+
+/* ---- parameter preparation ------------------------------------------------------------- */
+/* f32 weight [rows,cols] -> bf16 copy and/or bf16 transposed copy [cols,rows] (either may be NULL). */
+int scm_cast_weight(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
+/* FastAttention.projection_matrix f32 [266,64] (performer_pytorch.py:209) -> zero-padded bf16 [288,64]. */
+int scm_prep_omega(const float* omega, void* omega_b, void* stream);
+
+/* ---- embeddings: PerformerLM.forward performer_pytorch.py:604-607, Gene2VecPositionalEmbedding :444-446 -- */
+/* out[b,n,:] = f32( f64(E[tok[b,n],:]) + G[n,:] ); G (f64 [>=N, D]) may be NULL (no positional table).
+ * *err (device int, caller-zeroed) is set to 1 if a token id is outside [0,V). */
+int scm_embed_fwd(const int64_t* tok, const float* E, const double* G, int B, int N, int D, int V, float* out,
+                  int* err, void* stream);
+/* dE[v,:] (+)= sum of dx rows whose token id is v.  ws: scm_embed_bwd_ws_floats(T,D,V) floats. */
+int64_t scm_embed_bwd_ws_floats(int64_t T, int D, int V);
+int scm_embed_bwd(const int64_t* tok, const float* dx, int64_t T, int D, int V, float* ws, float* dE, int accumulate,
+                  void* stream);
+
+/* ---- LayerNorm of PreLayerNorm: performer_pytorch.py:289-295 (eps 1e-5, affine) ----------- */
+int scm_ln_fwd(const float* x, const float* gamma, const float* beta, int64_t T, int D, void* y_bf16, float* mean,
+               float* rstd, void* stream);
+/* dx = dres + dLN(dy) (dres may be NULL); dgamma/dbeta (+)= ; dres_colsum (+)= column sums of dres
+ * (the bias gradient of the Linear that produced the residual branch; may be NULL).
+ * ws: scm_ln_bwd_ws_floats(T,D) floats. */
+int64_t scm_ln_bwd_ws_floats(int64_t T, int D);
+int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+               const float* dres, int64_t T, int D, float* dx, float* ws, float* dgamma, float* dbeta,
+               float* dres_colsum, int accumulate, void* stream);
+
+/* ---- nn.Linear products: performer_pytorch.py:374 (to_q/k/v), :402 (to_out), :323,330 (FeedForward) ---- */
+/* Y[M,N] = A[M,K] * W[N,K]^T with a fused epilogue; A is bf16 or (a_f32) f32, W bf16, K % 8 == 0.
+ *   SCM_EPI_BF16          out0 bf16 = acc
+ *   SCM_EPI_F32_BIAS_RES  out0 f32  = acc + bias[n] + resid[m,n]     (bias/resid may be NULL; reversible.py:144-145)
+ *   SCM_EPI_GELU_DUAL     out0 bf16 = acc + bias ; out1 bf16 = gelu_erf(acc + bias)   (nn.GELU, :313)
+ *   SCM_EPI_DGELU         out0 bf16 = acc * gelu_erf'(pre[m,n])
+ *   SCM_EPI_F32           out0 f32  = acc
+ *   SCM_EPI_BF16_BIAS     out0 bf16 = acc + bias[n] */
+enum { SCM_EPI_BF16 = 0, SCM_EPI_F32_BIAS_RES = 1, SCM_EPI_GELU_DUAL = 2, SCM_EPI_DGELU = 3, SCM_EPI_F32 = 4,
+       SCM_EPI_BF16_BIAS = 5 };
+int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W_bf16, int64_t ldw, int M, int N, int K,
+                void* out0, int64_t ldo0, void* out1, int64_t ldo1, const float* bias, const float* resid,
+                int64_t ldr, const void* pre_bf16, int64_t ldp, void* stream);
+/* Weight gradient: G[P,Q] = sum_t Pm[t,P] * Qm[t,Q]; Pm bf16 (P % 8 == 0), Qm bf16 or (q_f32) f32, Q <= 200,
+ * Q % 8 == 0.  grad (+)= G, or G^T when trans (grad is [Q,P]).  bias_grad (may be NULL) (+)= column sums
+ * of Pm.  ws: scm_wgrad_ws_floats(P, slices) floats; slices token slices are reduced in a fixed order. */
+int64_t scm_wgrad_ws_floats(int P, int slices);
+int scm_wgrad(const void* Pm_bf16, int64_t ldp, const void* Qm, int64_t ldq, int q_f32, int64_t T, int P, int Q,
+              int slices, float* ws, float* grad, float* bias_grad, int trans, int accumulate, void* stream);
+
+/* ---- FAVOR+ attention: FastAttention.forward performer_pytorch.py:233-250 =
+ *      softmax_kernel (:67-92, query and key modes) + linear_attention (:144-149) --------------- */
+typedef struct {
+  int B, H, N;
+  int kmax_chunks; /* workgroups per (b,h) of the key-stabiliser pass */
+  int ctx_chunks;  /* token chunks per (b,h) of the K'^T V pass (partials in ws) */
+  int apply_chunks;/* token chunks per (b,h) of the output pass */
+} scm_favor_plan;
+/* fills the chunk counts for the MI355X (256 CUs) */
+int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan /* host */);
+int64_t scm_favor_ws_floats(const scm_favor_plan* plan /* host */);
+/* Saved state of one forward call (caller-allocated):
+ *   ctx_bf16 [B*H,288,64] bf16, z [B*H,288] f32, sums [B*H,80] f32, rowmax [B*H*N] f32, den [B*H*N] f32,
+ *   kmax [kmax_chunks*B*H] f32 (partial maxima; their max is the key stabiliser of performer_pytorch.py:90),
+ *   kmax_idx [kmax_chunks*B*H] i64 (where each partial maximum sits: (bh*N + n)*512 + feature). */
+int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, const void* omega_b,
+                  scm_view4 out, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
+                  int64_t* kmax_idx, float* ws, void* stream);
+/* Backward of the above: dq, dk, dv from dout, including the gradient that autograd routes through both
+ * stabilisers (per-token argmax for queries, the single global argmax for keys).  `o` is the forward output.
+ * Scratch: dctx_bf16/dz/dsums shaped like ctx_bf16/z/sums, dden [B*H*N]. */
+int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, scm_view4 o, scm_view4 dout,
+                  const void* omega_b, const void* ctx_bf16, const float* z, const float* sums, const float* rowmax,
+                  const float* den, const float* kmax, const int64_t* kmax_idx, scm_view4 dq, scm_view4 dk,
+                  scm_view4 dv, void* dctx_bf16, float* dz, float* dsums, float* dden, float* ws, void* stream);
+
+/* ---- final LayerNorm + head: performer_pytorch.py:628-634 (Linear(dim,num_tokens)); rna_encoder.py:5-16
+ *      (1x200 conv == dot product, + ReLU; C = 1, relu = 1) -------------------------------------- */
+/* enc (may be NULL) f32 [T,D] = LN(x); out (may be NULL when C == 0) f32 [T,C]. */
+int scm_head_fwd(const float* x, const float* gamma, const float* beta, const float* W, const float* bias, int64_t T,
+                 int D, int C, int relu, float* enc, float* out, float* mean, float* rstd, void* stream);
+int64_t scm_head_bwd_ws_floats(int64_t T, int D, int C);
+/* dout [T,C] and/or denc [T,D] (either may be NULL) -> dx; dgamma, dbeta, dW [C,D], db [C] (+)= . */
+int scm_head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
+                 const float* rstd, const float* gamma, const float* beta, const float* W, int64_t T, int D, int C,
+                 int relu, float* dx, float* ws, float* dgamma, float* dbeta, float* dW, float* db, int accumulate,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

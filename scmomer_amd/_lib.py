@@ -1,0 +1,77 @@
+"""ctypes binding of libscmomer_hip.so (C ABI declared in include/scmomer_hip.h).
+
+The library is the only compute path of this package: there is no CPU or eager fallback.
+If the shared object is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscmomer_hip.so")
+
+
+class View4(C.Structure):
+    """scm_view4: bf16 [B,H,N,64] view, strides in elements."""
+    _fields_ = [("p", C.c_void_p), ("sb", C.c_int64), ("sh", C.c_int64), ("sn", C.c_int64)]
+
+
+class FavorPlan(C.Structure):
+    """scm_favor_plan"""
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("kmax_chunks", C.c_int),
+                ("ctx_chunks", C.c_int), ("apply_chunks", C.c_int)]
+
+
+vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+
+# name -> (restype, argtypes); must list every symbol of include/scmomer_hip.h
+SIGNATURES = {
+    "scm_version": (i32, []),
+    "scm_last_error": (C.c_char_p, []),
+    "scm_cast_weight": (i32, [vp, i32, i32, vp, vp, vp]),
+    "scm_prep_omega": (i32, [vp, vp, vp]),
+    "scm_embed_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "scm_embed_bwd_ws_floats": (i64, [i64, i32, i32]),
+    "scm_embed_bwd": (i32, [vp, vp, i64, i32, i32, vp, vp, i32, vp]),
+    "scm_ln_fwd": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp]),
+    "scm_ln_bwd_ws_floats": (i64, [i64, i32]),
+    "scm_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp]),
+    "scm_gemm_nt": (i32, [i32, i32, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]),
+    "scm_wgrad_ws_floats": (i64, [i32, i32]),
+    "scm_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, i32, i32, vp]),
+    "scm_favor_make_plan": (i32, [i32, i32, i32, C.POINTER(FavorPlan)]),
+    "scm_favor_ws_floats": (i64, [C.POINTER(FavorPlan)]),
+    "scm_favor_fwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, vp, View4, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "scm_favor_bwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, View4, View4, vp, vp, vp, vp, vp, vp, vp, vp,
+                            View4, View4, View4, vp, vp, vp, vp, vp, vp]),
+    "scm_head_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "scm_head_bwd_ws_floats": (i64, [i64, i32, i32]),
+    "scm_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C scmomer_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class ScmError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib.scm_last_error().decode("utf-8", "replace")
+        raise ScmError(f"{what} failed ({code}): {msg}")

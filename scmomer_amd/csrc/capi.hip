@@ -1,0 +1,258 @@
+// extern "C" entry points of libscmomer_hip.so (declared in include/scmomer_hip.h):
+// argument validation + kernel sequencing.  No allocation, no device synchronisation.
+#include "scm_launch.hpp"
+#include "../../include/scmomer_hip.h"
+
+#include <stdio.h>
+#include <stdarg.h>
+
+using namespace scm;
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return SCM_EINVAL;
+}
+static int hipfail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+#define SCM_HIP(call, what)                          \
+  do {                                               \
+    hipError_t e__ = (call);                         \
+    if (e__ != hipSuccess) return hipfail(e__, what); \
+  } while (0)
+#define SCM_REQ(cond, ...) \
+  do {                     \
+    if (!(cond)) return fail(__VA_ARGS__); \
+  } while (0)
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static bool view_ok(const scm_view4& v) {
+  return v.p && aligned16(v.p) && v.sb % 8 == 0 && v.sh % 8 == 0 && v.sn % 8 == 0;
+}
+static TensorBHND cview(const scm_view4& v) { return {(const bf16*)v.p, (long)v.sb, (long)v.sh, (long)v.sn}; }
+static TensorBHND_out oview(const scm_view4& v) { return {(bf16*)v.p, (long)v.sb, (long)v.sh, (long)v.sn}; }
+
+extern "C" {
+
+int scm_version(void) { return 1; }
+const char* scm_last_error(void) { return g_err; }
+
+int scm_cast_weight(const float* src, int rows, int cols, void* dst, void* dstT, void* stream) {
+  SCM_REQ(src && rows > 0 && cols > 0 && (dst || dstT), "scm_cast_weight: bad arguments");
+  SCM_HIP(cast_weight(src, rows, cols, dst, dstT, (hipStream_t)stream), "scm_cast_weight");
+  return 0;
+}
+
+int scm_prep_omega(const float* omega, void* omega_b, void* stream) {
+  SCM_REQ(omega && omega_b && aligned16(omega_b), "scm_prep_omega: null or unaligned pointer");
+  SCM_HIP(favor_prep_omega(omega, omega_b, (hipStream_t)stream), "scm_prep_omega");
+  return 0;
+}
+
+int scm_embed_fwd(const int64_t* tok, const float* E, const double* G, int B, int N, int D, int V, float* out,
+                  int* err, void* stream) {
+  SCM_REQ(tok && E && out && err, "scm_embed_fwd: null pointer");
+  SCM_REQ(B > 0 && N > 0 && D > 0 && D <= 256 && D % 4 == 0 && V > 0 && V <= 8,
+          "scm_embed_fwd: need 0<D<=256, D%%4==0, 0<V<=8 (got D=%d V=%d)", D, V);
+  SCM_REQ(aligned16(E) && aligned16(out), "scm_embed_fwd: E/out must be 16-byte aligned");
+  SCM_HIP(embed_fwd(tok, E, G, B, N, D, V, out, err, (hipStream_t)stream), "scm_embed_fwd");
+  return 0;
+}
+
+int64_t scm_embed_bwd_ws_floats(int64_t T, int D, int V) { return (int64_t)embed_bwd_blocks(T) * V * D; }
+
+int scm_embed_bwd(const int64_t* tok, const float* dx, int64_t T, int D, int V, float* ws, float* dE, int accumulate,
+                  void* stream) {
+  SCM_REQ(tok && dx && ws && dE, "scm_embed_bwd: null pointer");
+  SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0 && V > 0 && V <= 8, "scm_embed_bwd: bad sizes");
+  SCM_HIP(embed_bwd(tok, dx, T, D, V, ws, (hipStream_t)stream), "scm_embed_bwd");
+  SCM_HIP(colsum_reduce(ws, embed_bwd_blocks(T), V * D, 0, V * D, dE, accumulate, (hipStream_t)stream),
+          "scm_embed_bwd(reduce)");
+  return 0;
+}
+
+int scm_ln_fwd(const float* x, const float* gamma, const float* beta, int64_t T, int D, void* y, float* mean,
+               float* rstd, void* stream) {
+  SCM_REQ(x && gamma && beta && y && mean && rstd, "scm_ln_fwd: null pointer");
+  SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0, "scm_ln_fwd: need 0<D<=256, D%%4==0 (got %d)", D);
+  SCM_REQ(aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(y), "scm_ln_fwd: unaligned pointer");
+  SCM_HIP(ln_fwd(x, gamma, beta, T, D, y, mean, rstd, (hipStream_t)stream), "scm_ln_fwd");
+  return 0;
+}
+
+int64_t scm_ln_bwd_ws_floats(int64_t T, int D) { return (int64_t)ln_bwd_blocks(T) * 3 * D; }
+
+int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+               const float* dres, int64_t T, int D, float* dx, float* ws, float* dgamma, float* dbeta,
+               float* dres_colsum, int accumulate, void* stream) {
+  SCM_REQ(dy && x && mean && rstd && gamma && dx && ws, "scm_ln_bwd: null pointer");
+  SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0, "scm_ln_bwd: bad sizes");
+  SCM_REQ(aligned16(dy) && aligned16(x) && aligned16(gamma) && aligned16(dx) && (!dres || aligned16(dres)),
+          "scm_ln_bwd: unaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  SCM_HIP(ln_bwd(dy, x, mean, rstd, gamma, dres, T, D, dx, ws, s), "scm_ln_bwd");
+  const int nb = ln_bwd_blocks(T);
+  if (dgamma) SCM_HIP(colsum_reduce(ws, nb, 3 * D, 0, D, dgamma, accumulate, s), "scm_ln_bwd(dgamma)");
+  if (dbeta) SCM_HIP(colsum_reduce(ws, nb, 3 * D, D, 2 * D, dbeta, accumulate, s), "scm_ln_bwd(dbeta)");
+  if (dres_colsum) SCM_HIP(colsum_reduce(ws, nb, 3 * D, 2 * D, 3 * D, dres_colsum, accumulate, s), "scm_ln_bwd(dres)");
+  return 0;
+}
+
+int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
+                void* out0, int64_t ldo0, void* out1, int64_t ldo1, const float* bias, const float* resid, int64_t ldr,
+                const void* pre, int64_t ldp, void* stream) {
+  SCM_REQ(A && W && out0, "scm_gemm_nt: null pointer");
+  SCM_REQ(M > 0 && N > 0 && K > 0 && K % 8 == 0, "scm_gemm_nt: need K%%8==0 (M=%d N=%d K=%d)", M, N, K);
+  SCM_REQ(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "scm_gemm_nt: lda/ldw must be >=K and %%8==0");
+  SCM_REQ(aligned16(A) && aligned16(W), "scm_gemm_nt: A/W must be 16-byte aligned");
+  SCM_REQ(epi >= 0 && epi <= 5, "scm_gemm_nt: unknown epilogue %d", epi);
+  SCM_REQ(ldo0 >= N, "scm_gemm_nt: ldo0 < N");
+  if (epi == SCM_EPI_GELU_DUAL) SCM_REQ(out1 && ldo1 >= N, "scm_gemm_nt: GELU_DUAL needs out1");
+  if (epi == SCM_EPI_DGELU) SCM_REQ(pre && ldp >= N, "scm_gemm_nt: DGELU needs pre");
+  if (resid) SCM_REQ(ldr >= N, "scm_gemm_nt: ldr < N");
+  GemmEpi e{out0, (long)ldo0, out1, (long)ldo1, bias, resid, (long)ldr, (const bf16*)pre, (long)ldp};
+  SCM_HIP(gemm_nt(epi, a_f32, A, lda, W, ldw, M, N, K, e, (hipStream_t)stream), "scm_gemm_nt");
+  return 0;
+}
+
+int64_t scm_wgrad_ws_floats(int P, int slices) { return (int64_t)slices * P * W_LDSLAB; }
+
+int scm_wgrad(const void* Pm, int64_t ldp, const void* Qm, int64_t ldq, int q_f32, int64_t T, int P, int Q,
+              int slices, float* ws, float* grad, float* bias_grad, int trans, int accumulate, void* stream) {
+  SCM_REQ(Pm && Qm && ws && grad, "scm_wgrad: null pointer");
+  SCM_REQ(T > 0 && T < (1ll << 31) && P > 0 && P % 8 == 0 && Q > 0 && Q <= 200 && Q % 8 == 0 && slices > 0,
+          "scm_wgrad: need P%%8==0, Q<=200, Q%%8==0 (P=%d Q=%d)", P, Q);
+  SCM_REQ(ldp % 8 == 0 && ldp >= P && ldq >= Q && ldq % 8 == 0 && aligned16(Pm) && aligned16(Qm),
+          "scm_wgrad: bad leading dimension or alignment");
+  hipStream_t s = (hipStream_t)stream;
+  SCM_HIP(wgrad(Pm, ldp, Qm, ldq, q_f32, bias_grad ? 1 : 0, (int)T, P, Q, slices, ws, s), "scm_wgrad");
+  SCM_HIP(wgrad_reduce(ws, slices, P, Q, grad, bias_grad, trans, accumulate, s), "scm_wgrad(reduce)");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- FAVOR+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan) {
+  SCM_REQ(plan && B > 0 && H > 0 && N > 0, "scm_favor_make_plan: bad arguments");
+  const int bh = B * H;
+  const int cus = 256;
+  plan->B = B; plan->H = H; plan->N = N;
+  // output pass: one 8-wave workgroup per CU (LDS bound) -> at most one round of workgroups
+  plan->apply_chunks = clampi(cus / bh, 1, (N + 31) / 32);
+  // context pass: 9-wave workgroups, up to 3 per CU; partial records cost 75 KB each
+  plan->ctx_chunks = clampi((2 * cus) / bh, 1, (N + 63) / 64);
+  plan->kmax_chunks = clampi((4 * cus) / bh, 1, (N + 127) / 128);
+  return 0;
+}
+
+int64_t scm_favor_ws_floats(const scm_favor_plan* p) {
+  if (!p) return 0;
+  return (int64_t)p->B * p->H * p->ctx_chunks * CTX_PART;
+}
+
+static int plan_ok(const scm_favor_plan* p) {
+  return p && p->B > 0 && p->H > 0 && p->N > 0 && p->kmax_chunks > 0 && p->ctx_chunks > 0 && p->apply_chunks > 0 &&
+         (int64_t)p->B * p->H <= 65535 && (int64_t)p->B * p->H * p->N < (1ll << 31);
+}
+
+int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, const void* omega_b,
+                  scm_view4 out, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
+                  int64_t* kmax_idx, float* ws, void* stream) {
+  SCM_REQ(plan_ok(plan), "scm_favor_fwd: bad plan");
+  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(out), "scm_favor_fwd: bad tensor view (null/unaligned)");
+  SCM_REQ(omega_b && ctx_bf16 && z && sums && rowmax && den && kmax && kmax_idx && ws, "scm_favor_fwd: null pointer");
+  SCM_REQ(aligned16(omega_b) && aligned16(ctx_bf16), "scm_favor_fwd: unaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = plan->B, H = plan->H, N = plan->N;
+  SCM_HIP(favor_kmax(cview(k), omega_b, B, H, N, plan->kmax_chunks, kmax, (long long*)kmax_idx, s), "favor_kmax");
+  CtxArgs c{};
+  c.x = cview(k); c.y = cview(v); c.omega_b = (const bf16*)omega_b;
+  c.stab = kmax; c.nstab = plan->kmax_chunks * B * H; c.den = nullptr; c.dden = nullptr;
+  c.H = H; c.N = N; c.part = ws;
+  SCM_HIP(favor_ctx(0, c, B, plan->ctx_chunks, s), "favor_ctx");
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, ctx_bf16, z, sums, s), "favor_ctx_finalize");
+  ApplyArgs a{};
+  a.x = cview(q); a.omega_b = (const bf16*)omega_b; a.Mb = (const bf16*)ctx_bf16; a.zf = z; a.sums = sums;
+  a.out0 = oview(out); a.rowmax_out = rowmax; a.den_out = den; a.H = H; a.N = N;
+  SCM_HIP(favor_apply(0, a, B, plan->apply_chunks, s), "favor_apply");
+  return 0;
+}
+
+int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, scm_view4 o, scm_view4 dout,
+                  const void* omega_b, const void* ctx_bf16, const float* z, const float* sums, const float* rowmax,
+                  const float* den, const float* kmax, const int64_t* kmax_idx, scm_view4 dq, scm_view4 dk,
+                  scm_view4 dv, void* dctx_bf16, float* dz, float* dsums, float* dden, float* ws, void* stream) {
+  SCM_REQ(plan_ok(plan), "scm_favor_bwd: bad plan");
+  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(o) && view_ok(dout) && view_ok(dq) && view_ok(dk) &&
+              view_ok(dv), "scm_favor_bwd: bad tensor view (null/unaligned)");
+  SCM_REQ(omega_b && ctx_bf16 && z && sums && rowmax && den && kmax && kmax_idx && dctx_bf16 && dz && dsums &&
+              dden && ws, "scm_favor_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = plan->B, H = plan->H, N = plan->N;
+  // 1. query side: dq and dden (needs C, z of the forward)
+  ApplyArgs a{};
+  a.x = cview(q); a.y = cview(dout); a.y2 = cview(o); a.omega_b = (const bf16*)omega_b; a.Mb = (const bf16*)ctx_bf16;
+  a.zf = z; a.sums = sums; a.stab = rowmax; a.den_in = den; a.out0 = oview(dq); a.dden_out = dden; a.H = H; a.N = N;
+  SCM_HIP(favor_apply(1, a, B, plan->apply_chunks, s), "favor_apply(dq)");
+  // 2. dC, dz = sum over tokens of the query features against dO/den and dden
+  CtxArgs c{};
+  c.x = cview(q); c.y = cview(dout); c.omega_b = (const bf16*)omega_b; c.stab = rowmax; c.nstab = 0; c.den = den;
+  c.dden = dden; c.H = H; c.N = N; c.part = ws;
+  SCM_HIP(favor_ctx(1, c, B, plan->ctx_chunks, s), "favor_ctx(dC)");
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, dctx_bf16, dz, dsums, s), "favor_ctx_finalize(dC)");
+  // 3. key side: dk, dv
+  ApplyArgs g{};
+  g.x = cview(k); g.y = cview(v); g.omega_b = (const bf16*)omega_b; g.Mb = (const bf16*)dctx_bf16; g.zf = dz;
+  g.sums = dsums; g.stab = kmax; g.nstab = plan->kmax_chunks * B * H; g.out0 = oview(dk); g.out1 = oview(dv);
+  g.H = H; g.N = N;
+  g.ksum_part = ws;  // the chunk partials in ws were consumed by the finalize step above
+  SCM_HIP(favor_apply(2, g, B, plan->apply_chunks, s), "favor_apply(dk,dv)");
+  // 4. gradient through the global key stabiliser lands on one token
+  SCM_HIP(favor_kfix(kmax, (const long long*)kmax_idx, g.nstab, ws, plan->apply_chunks * B * H, omega_b, oview(dk), H,
+                     N, s), "favor_kfix");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- head
+int scm_head_fwd(const float* x, const float* gamma, const float* beta, const float* W, const float* bias, int64_t T,
+                 int D, int C, int relu, float* enc, float* out, float* mean, float* rstd, void* stream) {
+  SCM_REQ(x && gamma && beta && mean && rstd && (enc || out), "scm_head_fwd: null pointer");
+  SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0 && C >= 0 && C <= 8, "scm_head_fwd: need D<=256, C<=8");
+  SCM_REQ(!out || (W && bias && C > 0), "scm_head_fwd: out needs W, bias and C>0");
+  SCM_REQ(aligned16(x) && aligned16(gamma) && aligned16(beta) && (!W || aligned16(W)) && (!enc || aligned16(enc)),
+          "scm_head_fwd: unaligned pointer");
+  SCM_HIP(head_fwd(x, gamma, beta, W, bias, T, D, out ? C : 0, relu, enc, out, mean, rstd, (hipStream_t)stream),
+          "scm_head_fwd");
+  return 0;
+}
+
+static int head_width(int D, int C) { return 2 * D + C * D + C; }
+int64_t scm_head_bwd_ws_floats(int64_t T, int D, int C) { return (int64_t)ln_bwd_blocks(T) * head_width(D, C); }
+
+int scm_head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
+                 const float* rstd, const float* gamma, const float* beta, const float* W, int64_t T, int D, int C,
+                 int relu, float* dx, float* ws, float* dgamma, float* dbeta, float* dW, float* db, int accumulate,
+                 void* stream) {
+  SCM_REQ(x && mean && rstd && gamma && beta && dx && ws && (dout || denc), "scm_head_bwd: null pointer");
+  SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0 && C >= 0 && C <= 8, "scm_head_bwd: need D<=256, C<=8");
+  SCM_REQ(!dout || (W && C > 0 && (!relu || out)), "scm_head_bwd: dout needs W (and out when relu)");
+  if (!dout) C = 0;
+  hipStream_t s = (hipStream_t)stream;
+  SCM_HIP(head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, W, T, D, C, relu, dx, ws, s), "scm_head_bwd");
+  const int nb = ln_bwd_blocks(T), wd = head_width(D, C);
+  if (dgamma) SCM_HIP(colsum_reduce(ws, nb, wd, 0, D, dgamma, accumulate, s), "scm_head_bwd(dgamma)");
+  if (dbeta) SCM_HIP(colsum_reduce(ws, nb, wd, D, 2 * D, dbeta, accumulate, s), "scm_head_bwd(dbeta)");
+  if (dW && C > 0) SCM_HIP(colsum_reduce(ws, nb, wd, 2 * D, 2 * D + C * D, dW, accumulate, s), "scm_head_bwd(dW)");
+  if (db && C > 0) SCM_HIP(colsum_reduce(ws, nb, wd, 2 * D + C * D, wd, db, accumulate, s), "scm_head_bwd(db)");
+  return 0;
+}
+
+}  // extern "C"

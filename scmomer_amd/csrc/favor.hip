@@ -1,0 +1,706 @@
+// FAVOR+ attention (softmax_kernel + linear_attention, performer_pytorch.py:67-92,144-149)
+// forward and backward for head dim 64 and 266 random features, bf16 MFMA with f32 accumulate.
+//
+// Notation per (cell b, head h), c = 64^-1/4, eps = 1e-4; the 266^-1/2 ratio of the reference
+// cancels between numerator and denominator and never appears:
+//   Eq[n,m] = exp(c*q_n.w_m - c^2/2 |q_n|^2 - c*max_m(q_n.w_m))          queries: per-token stabiliser
+//   Ek[n,m] = exp(c*k_n.w_m - c^2/2 |k_n|^2 - c*max_{b,h,n,m}(k_n.w_m))  keys: ONE stabiliser per call
+//   C[m,:] = sum_n (Ek+eps) v_n     z[m] = sum_n (Ek+eps)
+//   o_n = ((Eq+eps) C) / ((Eq+eps) z)
+// The eps terms are carried analytically (column sums) so the MFMA operands are pure
+// exponentials, whose bf16 rounding is relative at any magnitude.
+//
+// Kernels
+//   favor_kmax          max of k.w over the whole local batch -> per-workgroup partial maxima
+//   favor_ctx<MODE>     "feature-stationary": wave w owns features 32w..32w+31 (its slice of the
+//                       projection matrix stays in registers) and accumulates its 32x64 slice of
+//                       sum_n E[n,:]^T y_n over a token chunk.  MODE 0: (k, v) -> C, z.
+//                       MODE 1: (q, dO/den) -> dC, dz for the backward.
+//   favor_ctx_finalize  sums chunk partials, adds the eps terms, emits bf16 image + f32 vectors
+//   favor_apply<MODE>   "token-stationary": a wave owns 32 tokens (token = MFMA column, features
+//                       in accumulator rows) so every later product contracts over accumulator
+//                       rows with no lane movement.  MODE 0: o, rowmax, den.  MODE 1: dq, dden.
+//                       MODE 2: dk, dv.
+#include "scm_launch.hpp"
+
+namespace scm {
+
+constexpr int STAGE_PITCH = 68;                     // floats per staged output row (64 + 4 spare)
+
+SCM_DEV void load_image(char* img, const bf16* __restrict__ src /*[288][64]*/, int tid, int nthreads) {
+  for (int c = tid; c < NFP * 8; c += nthreads) {
+    const int row = c >> 3, ch = c & 7;
+    *(bf16x8*)(img + img_off(row, 8 * ch)) = *(const bf16x8*)(src + row * 64 + 8 * ch);
+  }
+}
+
+SCM_DEV float reduce_partial_max(const float* __restrict__ part, int n) {
+  float m = -INFINITY;
+  for (int i = lane_id(); i < n; i += 64) m = fmaxf(m, part[i]);
+  return wave_max(m);
+}
+
+SCM_DEV bf16x8 zero_frag() {
+  bf16x8 z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+  return z;
+}
+
+// fragment of x^T as MFMA B operand (k = d, column = token): 16 bytes of the lane's token row
+SCM_DEV void load_token_frags(bf16x8 (&f)[4], const bf16* __restrict__ row, bool valid) {
+  const int half = lane_id() >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = valid ? *(const bf16x8*)(row + 16 * ks + 8 * half) : zero_frag();
+}
+
+SCM_DEV float frag_sumsq(const bf16x8 (&f)[4]) {
+  float s = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = (float)f[ks][j]; s += v * v; }
+  return xhalf_sum(s);
+}
+
+// X[m,token] tile t = Omega_t (32x64) * x^T (64x32)
+SCM_DEV f32x16 score_tile(const char* omg, int t, const bf16x8 (&xf)[4]) {
+  f32x16 x = zero16();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) x = mfma32(img_row_frag(omg, 32 * t, 16 * ks), xf[ks], x);
+  return x;
+}
+
+// feature index of accumulator element r in tile t; valid iff < 266
+SCM_DEV bool feat_valid(int t, int r, int half) { return t < NFT - 1 || acc_row(r, half) < NF - 32 * (NFT - 1); }
+
+// ------------------------------------------------------------------------------------------
+// prep: f32 projection matrix [266][64] -> zero padded bf16 [288][64]
+// ------------------------------------------------------------------------------------------
+__global__ void favor_prep_omega_kernel(const float* __restrict__ omega, bf16* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NFP * DH) return;
+  out[i] = (bf16)((i < NF * DH) ? omega[i] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// key stabiliser: max over (b,h,n,m) of k_n.w_m (raw, before the c scale)
+// ------------------------------------------------------------------------------------------
+// (value, key) argmax combine: larger value wins, equal values keep the smaller key (first index)
+SCM_DEV void argmax_combine(float& v, long long& key, float ov, long long okey) {
+  if (ov > v || (ov == v && okey < key)) { v = ov; key = okey; }
+}
+SCM_DEV void wave_argmax(float& v, long long& key) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(v, o);
+    const int lo = __shfl_xor((int)(key & 0xffffffffll), o);
+    const int hi = __shfl_xor((int)(key >> 32), o);
+    argmax_combine(v, key, ov, ((long long)hi << 32) | (unsigned int)lo);
+  }
+}
+
+// part_val[wg] = max over the workgroup's tokens, part_key[wg] = (bh*N + n) * 512 + feature of the
+// first element attaining it (row-major order of the reference's [B,H,N,M] tensor).
+__global__ __launch_bounds__(256) void favor_kmax_kernel(TensorBHND k, const bf16* __restrict__ omega_b, int H, int N,
+                                                         int chunk_len, float* __restrict__ part_val,
+                                                         long long* __restrict__ part_key) {
+  __shared__ __attribute__((aligned(16))) char omg[NFP * 128];
+  __shared__ float wmax[4];
+  __shared__ long long wkey[4];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  load_image(omg, omega_b, tid, 256);
+  __syncthreads();
+  const int n_lo = blockIdx.x * chunk_len, n_hi = min(N, n_lo + chunk_len);
+  const bf16* base = k.p + b * k.sb + h * k.sh;
+  float mx = -INFINITY;
+  long long key = 0x7fffffffffffffffll;
+  for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 128) {
+    const int n = n0 + (l & 31);
+    const bool valid = n < n_hi;
+    bf16x8 kf[4];
+    load_token_frags(kf, base + (long)n * k.sn, valid);
+    float m = -INFINITY;
+    int feat = 0;
+#pragma unroll
+    for (int t = 0; t < NFT; ++t) {
+      f32x16 x = score_tile(omg, t, kf);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (feat_valid(t, r, half) && x[r] > m) { m = x[r]; feat = 32 * t + acc_row(r, half); }
+    }
+    if (valid) argmax_combine(mx, key, m, ((long long)bh * N + n) * 512 + feat);
+  }
+  wave_argmax(mx, key);
+  if (l == 0) { wmax[w] = mx; wkey[w] = key; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 4; ++i) argmax_combine(mx, key, wmax[i], wkey[i]);
+    part_val[blockIdx.y * gridDim.x + blockIdx.x] = mx;
+    part_key[blockIdx.y * gridDim.x + blockIdx.x] = key;
+  }
+}
+
+// Gradient through the key stabiliser (torch.max over the whole tensor, performer_pytorch.py:90):
+// dk[b*,h*,n*,:] += -c * (sum over everything of E * dE') * Omega[j*,:] at the argmax element.
+__global__ __launch_bounds__(64) void favor_kfix_kernel(const float* __restrict__ part_val,
+                                                        const long long* __restrict__ part_key, int nstab,
+                                                        const float* __restrict__ ksum_part, int nsum,
+                                                        const bf16* __restrict__ omega_b, TensorBHND_out dk, int H,
+                                                        int N) {
+  const int l = threadIdx.x;
+  float tot = 0.f;
+  for (int i = l; i < nsum; i += 64) tot += ksum_part[i];
+  tot = wave_sum(tot);
+  float mx = -INFINITY;
+  long long key = 0x7fffffffffffffffll;
+  for (int i = l; i < nstab; i += 64) argmax_combine(mx, key, part_val[i], part_key[i]);
+  wave_argmax(mx, key);
+  if (!(mx > -INFINITY)) return;
+  const int feat = (int)(key & 511);
+  const long long tl = key >> 9;
+  const int bh = (int)(tl / N), n = (int)(tl % N), b = bh / H, h = bh % H;
+  bf16* p = dk.p + b * dk.sb + h * dk.sh + (long)n * dk.sn + l;
+  *p = (bf16)((float)*p - CNORM * tot * (float)omega_b[feat * DH + l]);
+}
+
+// ------------------------------------------------------------------------------------------
+// favor_ctx: partial[bh][chunk] = { sum_n E[n,m] y[n,d] , sum_n E[n,m] w_n , sum_n y[n,d] , sum_n w_n }
+// ------------------------------------------------------------------------------------------
+constexpr int CTX_TILE = 64;
+constexpr int CTX_BUF = 2 * CTX_TILE * 128 + 2 * CTX_TILE * 4;  // x image, y image, off[], wgt[]
+
+template <int MODE>
+__global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ysum_s = (float*)(smem + 2 * CTX_BUF);  // [64] then wsum at [64]; all LDS is dynamic
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int n_lo = blockIdx.x * a.chunk_len, n_hi = min(a.N, n_lo + a.chunk_len);
+  const bool loader = tid < 512;
+  const int lrow = tid >> 3, lch = tid & 7;
+
+  if (tid <= DH) ysum_s[tid] = 0.f;
+
+  float gstab = 0.f;
+  if (MODE == 0) gstab = reduce_partial_max(a.stab, a.nstab);
+
+  // this wave's slice of the projection matrix as MFMA B operand (k = d, column = feature)
+  bf16x8 omf[4];
+  {
+    const bf16* orow = a.omega_b + (32 * w + (l & 31)) * DH;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) omf[ks] = *(const bf16x8*)(orow + 16 * ks + 8 * half);
+  }
+  const bool lane_feat_valid = (32 * w + (l & 31)) < NF;
+
+  f32x16 cacc[2] = {zero16(), zero16()};
+  float zacc = 0.f;
+  float ysum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ysum[j] = 0.f;
+  float wsum = 0.f;
+
+  const bf16* xb = a.x.p + b * a.x.sb + h * a.x.sh;
+  const bf16* yb = a.y.p + b * a.y.sb + h * a.y.sh;
+  const long srow = (long)bh * a.N;
+
+  bf16x8 xs_r, ys_r;
+  float st_r = 0.f, den_r = 1.f, w_r = 0.f;
+  bool val_r = false;
+  auto load_tile = [&](int n0) {
+    if (!loader) return;
+    const int n = n0 + lrow;
+    val_r = n < n_hi;
+    xs_r = zero_frag(); ys_r = zero_frag(); st_r = 0.f; den_r = 1.f; w_r = 0.f;
+    if (val_r) {
+      xs_r = *(const bf16x8*)(xb + (long)n * a.x.sn + 8 * lch);
+      ys_r = *(const bf16x8*)(yb + (long)n * a.y.sn + 8 * lch);
+      if (MODE == 1) { st_r = a.stab[srow + n]; den_r = a.den[srow + n]; w_r = a.dden[srow + n]; }
+    }
+  };
+  auto write_tile = [&](char* buf) {
+    if (!loader) return;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = (float)xs_r[j]; ss += v * v; }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+    bf16x8 yv = ys_r;
+    if (MODE == 1) {
+      const float inv = 1.f / den_r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yv[j] = (bf16)((float)ys_r[j] * inv);
+    }
+    if (val_r) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ysum[j] += (float)yv[j];
+    }
+    *(bf16x8*)(buf + img_off(lrow, 8 * lch)) = xs_r;
+    *(bf16x8*)(buf + CTX_TILE * 128 + img_off(lrow, 8 * lch)) = yv;
+    if (lch == 0) {
+      const float stab = (MODE == 0) ? gstab : st_r;
+      float* off = (float*)(buf + 2 * CTX_TILE * 128);
+      off[lrow] = val_r ? (HALF_C2 * ss + CNORM * stab) * LOG2E : INFINITY;
+      off[CTX_TILE + lrow] = (MODE == 1) ? w_r : (val_r ? 1.f : 0.f);
+      if (MODE == 1) wsum += w_r;
+    }
+  };
+
+  const int ntiles = (n_hi - n_lo + CTX_TILE - 1) / CTX_TILE;
+  if (ntiles > 0) { load_tile(n_lo); write_tile(smem); }
+  __syncthreads();
+  for (int it = 0; it < ntiles; ++it) {
+    char* buf = smem + (it & 1) * CTX_BUF;
+    char* nbuf = smem + ((it + 1) & 1) * CTX_BUF;
+    if (it + 1 < ntiles) load_tile(n_lo + (it + 1) * CTX_TILE);
+    const char* xs = buf;
+    const char* ys = buf + CTX_TILE * 128;
+    const float* off = (const float*)(buf + 2 * CTX_TILE * 128);
+    const float* wg = off + CTX_TILE;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      // S[token, feature] = x_tile (32x64) * Omega_w^T (64x32)
+      f32x16 s = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = mfma32(img_row_frag(xs, 32 * sub, 16 * ks), omf[ks], s);
+      f32x16 e;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o4 = *(const f32x4*)(off + 32 * sub + 8 * g + 4 * half);
+        const f32x4 w4 = *(const f32x4*)(wg + 32 * sub + 8 * g + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = exp2_fast(s[4 * g + i] * (CNORM * LOG2E) - o4[i]);
+          v = lane_feat_valid ? v : 0.f;
+          e[4 * g + i] = v;
+          zacc += v * w4[i];
+        }
+      }
+      // C_w[feature, d] += E^T (32 features x 32 tokens) * y (32 tokens x 64)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 ef = acc_to_frag(e, sk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          cacc[dt] = mfma32(ef, img_tr_frag<true>(ys, 32 * sub + 16 * sk, 32 * dt), cacc[dt]);
+      }
+    }
+    if (it + 1 < ntiles) write_tile(nbuf);
+    __syncthreads();
+  }
+
+  // partial record
+  float* rec = a.part + ((long)bh * gridDim.x + blockIdx.x) * CTX_PART;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rec[(32 * w + acc_row(r, half)) * DH + 32 * dt + (l & 31)] = cacc[dt][r];
+  const float zt = xhalf_sum(zacc);
+  if (l < 32) rec[NFP * DH + 32 * w + l] = zt;
+  if (loader) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&ysum_s[8 * lch + j], ysum[j]);
+    if (MODE == 1 && lch == 0) atomicAdd(&ysum_s[DH], wsum);
+  }
+  __syncthreads();
+  if (tid < DH) rec[NFP * DH + NFP + tid] = ysum_s[tid];
+  if (tid == 0) rec[NFP * DH + NFP + DH] = (MODE == 1) ? ysum_s[DH] : (float)max(0, n_hi - n_lo);
+}
+
+// Sum chunk partials, add the analytic eps terms, write:
+//   Mb  bf16 [bh][288][64]   M[m,d] = sum_c CE + eps * ysum[d]       (0 for padded features)
+//   zf  f32  [bh][288]       z[m]   = sum_c zE + eps * wsum
+//   sums f32 [bh][80]        sums[d] = sum_m M[m,d] ; sums[64] = sum_m z[m]
+__global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __restrict__ part, int nchunks,
+                                                                 bf16* __restrict__ Mb, float* __restrict__ zf,
+                                                                 float* __restrict__ sums) {
+  __shared__ float ysum[DH];
+  __shared__ float wsum;
+  __shared__ float colp[4][DH];
+  __shared__ float zp[256];
+  const int tid = threadIdx.x, bh = blockIdx.x;
+  const float* base = part + (long)bh * nchunks * CTX_PART;
+  if (tid < DH) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NFP + tid];
+    ysum[tid] = s;
+  }
+  if (tid == 64) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NFP + DH];
+    wsum = s;
+  }
+  __syncthreads();
+  // thread -> column d = tid & 63, rows m = (tid >> 6) + 4*i
+  const int d = tid & 63, q = tid >> 6;
+  float csum = 0.f;
+  for (int m = q; m < NFP; m += 4) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + m * DH + d];
+    const float v = (m < NF) ? s + KEPS * ysum[d] : 0.f;
+    Mb[((long)bh * NFP + m) * DH + d] = (bf16)v;
+    csum += v;
+  }
+  colp[q][d] = csum;
+  float zs = 0.f;
+  for (int m = tid; m < NFP; m += 256) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + m];
+    const float v = (m < NF) ? s + KEPS * wsum : 0.f;
+    zf[(long)bh * NFP + m] = v;
+    zs += v;
+  }
+  zp[tid] = zs;
+  __syncthreads();
+  if (tid < DH) sums[(long)bh * SUMS_STRIDE + tid] = colp[0][tid] + colp[1][tid] + colp[2][tid] + colp[3][tid];
+  if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 256; ++i) s += zp[i];
+    sums[(long)bh * SUMS_STRIDE + DH] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// favor_apply
+// ------------------------------------------------------------------------------------------
+// stage[token][d..d+3] for the 4-register groups of a [d rows][token cols] accumulator pair
+SCM_DEV void stage_rows(float* stage, const f32x16 (&y)[2], float scale, const float* add4 /*LDS [64] or null*/,
+                        float addscale) {
+  const int l = lane_id(), tok = l & 31, half = l >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * dt + 8 * g + 4 * half;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = y[dt][4 * g + i] * scale;
+      if (add4) {
+        const f32x4 c4 = *(const f32x4*)(add4 + d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (y[dt][4 * g + i] + addscale * c4[i]) * scale;
+      }
+      *(f32x4*)(stage + tok * STAGE_PITCH + d) = v;
+    }
+}
+
+// coalesced write-back of a staged [32][64] f32 tile as bf16; optional rank-1 correction
+// out[row][d] = stage[row][d] + stage[row][64] * corr_scale * xrow[d]
+// and, with omg != null, + stage[row][65] * Omega[(int)stage[row][66]][d] (Omega from its LDS image)
+SCM_DEV void store_rows(const float* stage, bf16* __restrict__ obase, long osn, const bf16* __restrict__ xbase,
+                        long xsn, float corr_scale, int n0, int n_hi, const char* omg = nullptr) {
+  const int l = lane_id();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + (l >> 3), ch = l & 7;
+    const int n = n0 + row;
+    if (n < n_hi) {
+      const f32x4 a = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch);
+      const f32x4 b = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch + 4);
+      float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      if (xbase) {
+        const float cs = stage[row * STAGE_PITCH + 64] * corr_scale;
+        const bf16x8 xv = *(const bf16x8*)(xbase + (long)n * xsn + 8 * ch);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += cs * (float)xv[j];
+      }
+      if (omg) {
+        const float os = stage[row * STAGE_PITCH + 65];
+        const int jr = ((const int*)stage)[row * STAGE_PITCH + 66];
+        const bf16x8 ov = *(const bf16x8*)(omg + img_off(jr, 8 * ch));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += os * (float)ov[j];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+      *(bf16x8*)(obase + (long)n * osn + 8 * ch) = o;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* omg = smem;                                   // Omega image
+  char* mim = smem + NFP * 128;                       // C or dC image
+  float* zv = (float*)(smem + 2 * NFP * 128);         // [288]
+  float* sm = zv + NFP;                               // [80]
+  float* stage_all = sm + SUMS_STRIDE;                // 8 x [32][68]
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int n_lo = blockIdx.x * a.chunk_len, n_hi = min(a.N, n_lo + a.chunk_len);
+  float* stage = stage_all + w * 32 * STAGE_PITCH;
+
+  load_image(omg, a.omega_b, tid, 512);
+  load_image(mim, a.Mb + (long)bh * NFP * DH, tid, 512);
+  for (int i = tid; i < NFP; i += 512) zv[i] = a.zf[(long)bh * NFP + i];
+  if (tid < SUMS_STRIDE) sm[tid] = a.sums[(long)bh * SUMS_STRIDE + tid];
+  float gstab = 0.f;
+  if (MODE == 2) gstab = reduce_partial_max(a.stab, a.nstab);
+  __syncthreads();
+  const float zsum = sm[DH];
+
+  const bf16* xb = a.x.p + b * a.x.sb + h * a.x.sh;
+  const long srow = (long)bh * a.N;
+  float ksum = 0.f;  // MODE 2: sum over this wave's tokens of sum_m dA
+
+  for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 256) {
+    const int n = n0 + (l & 31);
+    const bool valid = n < n_hi;
+    bf16x8 xf[4];
+    load_token_frags(xf, xb + (long)n * a.x.sn, valid);
+    const float norm2 = frag_sumsq(xf);
+
+    if (MODE == 0) {
+      f32x16 X[NFT];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < NFT; ++t) {
+        X[t] = score_tile(omg, t, xf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (feat_valid(t, r, half)) mx = fmaxf(mx, X[t][r]);
+      }
+      mx = xhalf_max(mx);
+      const float off = (HALF_C2 * norm2 + CNORM * mx) * LOG2E;
+      f32x16 Y[2] = {zero16(), zero16()};
+      float dsum = 0.f;
+#pragma unroll
+      for (int t = 0; t < NFT; ++t) {
+        f32x16 e;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 z4 = *(const f32x4*)(zv + 32 * t + 8 * g + 4 * half);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            float v = exp2_fast(X[t][r] * (CNORM * LOG2E) - off);
+            v = feat_valid(t, r, half) ? v : 0.f;
+            e[r] = v;
+            dsum += v * z4[i];
+          }
+        }
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+          const bf16x8 ef = acc_to_frag(e, sk);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            Y[dt] = mfma32(img_tr_frag<true>(mim, 32 * t + 16 * sk, 32 * dt), ef, Y[dt]);
+        }
+      }
+      const float den = xhalf_sum(dsum) + KEPS * zsum;
+      const float inv = 1.f / den;
+      stage_rows(stage, Y, inv, sm, KEPS);
+      __builtin_amdgcn_wave_barrier();
+      bf16* ob = a.out0.p + b * a.out0.sb + h * a.out0.sh;
+      store_rows(stage, ob, a.out0.sn, nullptr, 0, 0.f, n0, n_hi);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && l < 32) { a.rowmax_out[srow + n] = mx; a.den_out[srow + n] = den; }
+    }
+
+    if (MODE == 1) {
+      const bf16* dob = a.y.p + b * a.y.sb + h * a.y.sh;
+      const bf16* ob = a.y2.p + b * a.y2.sb + h * a.y2.sh;
+      bf16x8 dof[4], of[4];
+      load_token_frags(dof, dob + (long)n * a.y.sn, valid);
+      load_token_frags(of, ob + (long)n * a.y2.sn, valid);
+      float delta = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[ks][j];
+      delta = xhalf_sum(delta);
+      const float den = valid ? a.den_in[srow + n] : 1.f;
+      const float rmx = valid ? a.stab[srow + n] : 0.f;
+      const float inv = 1.f / den;
+      const float dden = -delta * inv;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dof[ks][j] = (bf16)((float)dof[ks][j] * inv);
+      const float off = (HALF_C2 * norm2 + CNORM * rmx) * LOG2E;
+      f32x16 Y[2] = {zero16(), zero16()};
+      float rs = 0.f;
+      int jstar = 1 << 20;
+#pragma unroll 1
+      for (int t = 0; t < NFT; ++t) {
+        const f32x16 X = score_tile(omg, t, xf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (feat_valid(t, r, half) && X[r] == rmx) jstar = min(jstar, 32 * t + acc_row(r, half));
+        // G[m,token] = C_t (32x64) * dnum^T (64x32) + z[m] * dden
+        f32x16 G = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) G = mfma32(img_row_frag(mim, 32 * t, 16 * ks), dof[ks], G);
+        f32x16 dA;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 z4 = *(const f32x4*)(zv + 32 * t + 8 * g + 4 * half);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            float e = exp2_fast(X[r] * (CNORM * LOG2E) - off);
+            e = feat_valid(t, r, half) ? e : 0.f;
+            const float v = e * (G[r] + z4[i] * dden);
+            dA[r] = v;
+            rs += v;
+          }
+        }
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+          const bf16x8 af = acc_to_frag(dA, sk);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            Y[dt] = mfma32(img_tr_frag<true>(omg, 32 * t + 16 * sk, 32 * dt), af, Y[dt]);
+        }
+      }
+      const float ddiag = -xhalf_sum(rs);
+      jstar = min(jstar, __shfl_xor(jstar, 32));
+      stage_rows(stage, Y, CNORM, nullptr, 0.f);
+      if (l < 32) {
+        stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
+        // stabiliser gradient: rowmax = S[n, j*]  =>  dq += c * ddiag * Omega[j*]
+        stage[(l & 31) * STAGE_PITCH + 65] = (jstar < NF) ? CNORM * ddiag : 0.f;
+        ((int*)stage)[(l & 31) * STAGE_PITCH + 66] = (jstar < NF) ? jstar : 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      bf16* dqb = a.out0.p + b * a.out0.sb + h * a.out0.sh;
+      store_rows(stage, dqb, a.out0.sn, xb, a.x.sn, 2.f * HALF_C2, n0, n_hi, omg);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && l < 32) a.dden_out[srow + n] = dden;
+    }
+
+    if (MODE == 2) {
+      const bf16* vb = a.y.p + b * a.y.sb + h * a.y.sh;
+      bf16x8 vf[4];
+      load_token_frags(vf, vb + (long)n * a.y.sn, valid);
+      const float off = (HALF_C2 * norm2 + CNORM * gstab) * LOG2E;
+      f32x16 Yk[2] = {zero16(), zero16()};
+      f32x16 Yv[2] = {zero16(), zero16()};
+      float rs = 0.f;
+#pragma unroll 1
+      for (int t = 0; t < NFT; ++t) {
+        const f32x16 X = score_tile(omg, t, xf);
+        // G[m,token] = dC_t (32x64) * v^T (64x32) + dz[m]
+        f32x16 G = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) G = mfma32(img_row_frag(mim, 32 * t, 16 * ks), vf[ks], G);
+        f32x16 E, dA;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 z4 = *(const f32x4*)(zv + 32 * t + 8 * g + 4 * half);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            float e = exp2_fast(X[r] * (CNORM * LOG2E) - off);
+            e = feat_valid(t, r, half) ? e : 0.f;
+            E[r] = e;
+            const float v = e * (G[r] + z4[i]);
+            dA[r] = v;
+            rs += v;
+          }
+        }
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+          const bf16x8 af = acc_to_frag(dA, sk);
+          const bf16x8 ef = acc_to_frag(E, sk);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            Yk[dt] = mfma32(img_tr_frag<true>(omg, 32 * t + 16 * sk, 32 * dt), af, Yk[dt]);
+            Yv[dt] = mfma32(img_tr_frag<true>(mim, 32 * t + 16 * sk, 32 * dt), ef, Yv[dt]);
+          }
+        }
+      }
+      const float ddiag = -xhalf_sum(rs);
+      if (valid && l < 32) ksum -= ddiag;
+      // dv = E dC + eps * colsum(dC)
+      stage_rows(stage, Yv, 1.f, sm, KEPS);
+      __builtin_amdgcn_wave_barrier();
+      bf16* dvb = a.out1.p + b * a.out1.sb + h * a.out1.sh;
+      store_rows(stage, dvb, a.out1.sn, nullptr, 0, 0.f, n0, n_hi);
+      __builtin_amdgcn_wave_barrier();
+      stage_rows(stage, Yk, CNORM, nullptr, 0.f);
+      if (l < 32) stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
+      __builtin_amdgcn_wave_barrier();
+      bf16* dkb = a.out0.p + b * a.out0.sb + h * a.out0.sh;
+      store_rows(stage, dkb, a.out0.sn, xb, a.x.sn, 2.f * HALF_C2, n0, n_hi);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (MODE == 2) {
+    // fixed-order sum of the 8 wave totals -> one partial per workgroup
+    ksum = wave_sum(ksum);
+    __syncthreads();
+    if (l == 0) sm[w] = ksum;
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+      for (int i = 0; i < 8; ++i) s += sm[i];
+      a.ksum_part[blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s) {
+  hipLaunchKernelGGL(favor_prep_omega_kernel, dim3((NFP * DH + 255) / 256), dim3(256), 0, s, omega, (bf16*)out);
+  return hipGetLastError();
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, int nchunks, float* part,
+                      long long* part_key, hipStream_t s) {
+  const int chunk_len = round_up((N + nchunks - 1) / nchunks, 32);
+  hipLaunchKernelGGL(favor_kmax_kernel, dim3(nchunks, B * H), dim3(256), 0, s, k, (const bf16*)omega_b, H, N,
+                     chunk_len, part, part_key);
+  return hipGetLastError();
+}
+
+hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
+                      const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s) {
+  hipLaunchKernelGGL(favor_kfix_kernel, dim3(1), dim3(64), 0, s, part_val, part_key, nstab, ksum_part, nsum,
+                     (const bf16*)omega_b, dk, H, N);
+  return hipGetLastError();
+}
+
+hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
+  a.chunk_len = round_up((a.N + nchunks - 1) / nchunks, CTX_TILE);
+  const size_t lds = 2 * CTX_BUF + 80 * sizeof(float);
+  if (mode == 0)
+    hipLaunchKernelGGL((favor_ctx_kernel<0>), dim3(nchunks, B * a.H), dim3(576), lds, s, a);
+  else
+    hipLaunchKernelGGL((favor_ctx_kernel<1>), dim3(nchunks, B * a.H), dim3(576), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, void* Mb, float* zf, float* sums,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH), dim3(256), 0, s, part, nchunks, (bf16*)Mb, zf, sums);
+  return hipGetLastError();
+}
+
+size_t favor_apply_lds() { return 2 * NFP * 128 + (NFP + SUMS_STRIDE) * 4 + 8 * 32 * STAGE_PITCH * 4; }
+
+hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s) {
+  a.chunk_len = round_up((a.N + nchunks - 1) / nchunks, 32);
+  const size_t lds = favor_apply_lds();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)favor_apply_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)favor_apply_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)favor_apply_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(nchunks, B * a.H);
+  if (mode == 0) hipLaunchKernelGGL((favor_apply_kernel<0>), grid, dim3(512), lds, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((favor_apply_kernel<1>), grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((favor_apply_kernel<2>), grid, dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace scm

@@ -1,0 +1,128 @@
+// Shared device helpers for the gfx950 (MI355X) kernels of the Performer RNA-encoder path.
+// Wave = 64 lanes.  All matrix products use v_mfma_f32_32x32x16_bf16 (bf16 in, f32 accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scm {
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// model constants of the path (performer_pytorch.py:550,201; rna_encoder.py:29-37)
+constexpr int DH = 64;        // dim_head
+constexpr int NF = 266;       // nb_features = int(64 * ln 64)
+constexpr int NFP = 288;      // padded to 9 MFMA tiles of 32
+constexpr int NFT = NFP / 32; // 9
+constexpr float KEPS = 1e-4f; // softmax_kernel eps
+constexpr float LOG2E = 1.4426950408889634f;
+// data_normalizer = 64^-1/4 ; c^2/2 = 1/16
+constexpr float CNORM = 0.35355339059327373f;
+constexpr float HALF_C2 = 0.0625f;
+
+#define SCM_DEV __device__ __forceinline__
+
+SCM_DEV int lane_id() { return threadIdx.x & 63; }
+
+// D = A(32x16) * B(16x32) + C.  Lane l holds A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31], j=0..7.
+// C/D: element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+SCM_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+SCM_DEV int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+SCM_DEV f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+SCM_DEV float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+SCM_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+SCM_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+
+SCM_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+SCM_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Registers 8s..8s+7 of a 32x32 accumulator tile as the bf16 fragment of k-step s of a
+// following MFMA that contracts over the tile's ROW index.  Element j of lane-half h is row
+// 16s + 8(j>>2) + 4h + (j&3) of the tile: the other operand must use the same k order.
+SCM_DEV bf16x8 acc_to_frag(const f32x16& x, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16)x[8 * s + j];
+  return f;
+}
+
+// ---- LDS images with 128-byte rows (64 bf16), 16-byte chunks XOR-swizzled -----------------
+// chunk' = chunk ^ f(row), f(row) = (((row>>1)&1)<<2) | ((row>>2)&3).
+// Row reads (ds_read_b128, lanes = 32 consecutive rows, same chunk) and transposed reads
+// (ds_read_b64_tr_b16 of 4-row x 16-column blocks) are both bank-conflict free.
+SCM_DEV int swz128(int row, int chunk) {
+  return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+}
+// byte offset of element (row, col) in a swizzled [rows][64] bf16 image
+SCM_DEV int img_off(int row, int col) {
+  return row * 128 + swz128(row, col >> 3) * 16 + (col & 7) * 2;
+}
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// transposed 4x16 block read: returns, for this lane's column, the 4 consecutive rows.
+SCM_DEV bf16x4 lds_tr_read(const void* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds_ptr));
+}
+
+// Fragment (A operand rows = image columns, or B operand cols = image columns) whose k index
+// runs over image ROWS, read from a swizzled 128-byte-row image by two transposed reads.
+//   k order "natural":  element j <- row  kbase + 8*half + j
+//   k order "acc":      element j <- row  kbase + 8*(j>>2) + 4*half + (j&3)   (pairs with acc_to_frag)
+// col_base: first of the 32 image columns this fragment spans.
+template <bool ACC_ORDER>
+SCM_DEV bf16x8 img_tr_frag(const char* img, int kbase, int col_base) {
+  const int l = lane_id();
+  const int g = l >> 4, i = l & 15, half = g >> 1;
+  const int col = col_base + 16 * (g & 1) + 4 * (i & 3);
+  const int r0 = ACC_ORDER ? (kbase + 4 * half) : (kbase + 8 * half);
+  const int r1 = ACC_ORDER ? (kbase + 8 + 4 * half) : (kbase + 8 * half + 4);
+  const int q = i >> 2;
+  bf16x4 lo = lds_tr_read(img + img_off(r0 + q, col));
+  bf16x4 hi = lds_tr_read(img + img_off(r1 + q, col));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+// Fragment whose k index runs along image COLUMNS (contiguous): lane reads 16 bytes of row
+// row_base + (l&31) at columns kbase + 8*half .. +7.
+SCM_DEV bf16x8 img_row_frag(const char* img, int row_base, int kbase) {
+  const int l = lane_id();
+  const int row = row_base + (l & 31);
+  return *(const bf16x8*)(img + img_off(row, kbase + 8 * (l >> 5)));
+}
+
+SCM_DEV float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+SCM_DEV float gelu_erf_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+}  // namespace scm

@@ -1,0 +1,95 @@
+// Host-side launch interface shared by the kernel translation units and the C ABI wrappers.
+#pragma once
+#include "scm_common.hpp"
+
+namespace scm {
+
+struct GemmEpi {
+  void* out0; long ldo0;
+  void* out1; long ldo1;
+  const float* bias;
+  const float* resid; long ldr;
+  const bf16* pre; long ldp;
+};
+
+struct TensorBHND {  // element (b,h,n,d) at p + b*sb + h*sh + n*sn + d   (d contiguous)
+  const bf16* p; long sb, sh, sn;
+};
+struct TensorBHND_out { bf16* p; long sb, sh, sn; };
+
+constexpr int CTX_PART = NFP * DH + NFP + DH + 16;  // floats per (bh, chunk) partial record
+constexpr int SUMS_STRIDE = 80;                     // Csum[64], zsum at [64]
+
+struct CtxArgs {
+  TensorBHND x;          // MODE 0: k ; MODE 1: q
+  TensorBHND y;          // MODE 0: v ; MODE 1: dO
+  const bf16* omega_b;   // [288][64]
+  const float* stab;     // MODE 0: kmax partials ; MODE 1: rowmax [B*H*N]
+  int nstab;
+  const float* den;      // MODE 1: [B*H*N]
+  const float* dden;     // MODE 1: [B*H*N]
+  int H, N, chunk_len;   // chunk_len % 64 == 0
+  float* part;
+};
+
+struct ApplyArgs {
+  TensorBHND x;            // MODE 0,1: q ; MODE 2: k
+  TensorBHND y;            // MODE 1: dO ; MODE 2: v
+  TensorBHND y2;           // MODE 1: o (saved forward output)
+  const bf16* omega_b;     // [288][64]
+  const bf16* Mb;          // [bh][288][64]  MODE 0,1: C ; MODE 2: dC
+  const float* zf;         // [bh][288]      MODE 0,1: z ; MODE 2: dz
+  const float* sums;       // [bh][80]
+  const float* stab;       // MODE 1: rowmax [B*H*N] ; MODE 2: kmax partials
+  int nstab;
+  const float* den_in;     // MODE 1
+  TensorBHND_out out0;     // MODE 0: o ; MODE 1: dq ; MODE 2: dk
+  TensorBHND_out out1;     // MODE 2: dv
+  float* rowmax_out;       // MODE 0
+  float* den_out;          // MODE 0
+  float* dden_out;         // MODE 1
+  float* ksum_part;        // MODE 2: [workgroups] partial sums of E * dE' (key stabiliser gradient)
+  int H, N, chunk_len;     // chunk_len % 32 == 0
+};
+
+constexpr int W_LDSLAB = 208;   // floats per wgrad slab row
+
+// gemm.hip
+hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                   GemmEpi e, hipStream_t s);
+hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, int ones, int T, int P, int Q,
+                 int slices, float* slab, hipStream_t s);
+hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, float* bias, int trans, int accumulate,
+                        hipStream_t s);
+hipError_t cast_weight(const float* src, int R, int C, void* dst, void* dstT, hipStream_t s);
+
+// norm_embed.hip
+hipError_t embed_fwd(const int64_t* tok, const float* E, const double* G, int B, int N, int D, int V, float* out,
+                     int* err, hipStream_t s);
+int embed_bwd_blocks(long T);
+hipError_t embed_bwd(const int64_t* tok, const float* dx, long T, int D, int V, float* partial, hipStream_t s);
+hipError_t ln_fwd(const float* x, const float* g, const float* b, long T, int D, void* y, float* mean, float* rstd,
+                  hipStream_t s);
+int ln_bwd_blocks(long T);
+hipError_t ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                  const float* dres, long T, int D, float* dx, float* partial, hipStream_t s);
+hipError_t head_fwd(const float* x, const float* g, const float* b, const float* W, const float* bias, long T, int D,
+                    int C, int relu, float* enc, float* out, float* mean, float* rstd, hipStream_t s);
+hipError_t head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, const float* W, long T, int D, int C,
+                    int relu, float* dx, float* partial, hipStream_t s);
+hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, int hi, float* out, int accumulate,
+                         hipStream_t s);
+
+// favor.hip
+hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s);
+hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, int nchunks, float* part,
+                      long long* part_key, hipStream_t s);
+hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
+                      const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s);
+hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s);
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, void* Mb, float* zf, float* sums,
+                              hipStream_t s);
+hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s);
+
+}  // namespace scm

@@ -1,0 +1,226 @@
+"""Torch-tensor front end of the C ABI: allocates outputs/workspaces with torch (device memory
+and streams are torch's job here), passes raw device pointers and the current stream.
+
+Every function requires CUDA(HIP) tensors; nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import FavorPlan, View4, check, lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+EPI_BF16, EPI_F32_BIAS_RES, EPI_GELU_DUAL, EPI_DGELU, EPI_F32, EPI_BF16_BIAS = range(6)
+
+NB_FEATURES, NB_FEATURES_PAD, DIM_HEAD = 266, 288, 64
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "scmomer_amd ops need device tensors (no CPU path)"
+    return t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor; scmomer_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+def view4(t: torch.Tensor) -> View4:
+    """[B,H,N,64] bf16 view with arbitrary b/h/n strides (d contiguous)."""
+    if t.dtype != BF16 or t.dim() != 4 or t.shape[-1] != DIM_HEAD or t.stride(3) != 1:
+        raise ValueError(f"expected bf16 [B,H,N,64] with contiguous last dim, got {t.dtype} {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return View4(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+# ----------------------------------------------------------------------------- parameters
+def cast_weight(w: torch.Tensor, want_plain=True, want_t=True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    _req(w, F32, "weight")
+    r, c = w.shape
+    wb = torch.empty((r, c), dtype=BF16, device=w.device) if want_plain else None
+    wt = torch.empty((c, r), dtype=BF16, device=w.device) if want_t else None
+    check(lib.scm_cast_weight(_p(w), r, c, _p(wb), _p(wt), _stream()), "scm_cast_weight")
+    return wb, wt
+
+
+def prep_omega(omega: torch.Tensor) -> torch.Tensor:
+    _req(omega, F32, "projection_matrix")
+    if tuple(omega.shape) != (NB_FEATURES, DIM_HEAD):
+        raise ValueError(f"projection_matrix must be [266,64], got {tuple(omega.shape)}")
+    out = torch.empty((NB_FEATURES_PAD, DIM_HEAD), dtype=BF16, device=omega.device)
+    check(lib.scm_prep_omega(_p(omega), _p(out), _stream()), "scm_prep_omega")
+    return out
+
+
+# ----------------------------------------------------------------------------- embedding
+def embed_fwd(tok: torch.Tensor, emb: torch.Tensor, g2v: Optional[torch.Tensor]) -> torch.Tensor:
+    _req(tok, torch.int64, "tokens")
+    _req(emb, F32, "token_emb.weight")
+    b, n = tok.shape
+    v, d = emb.shape
+    if g2v is not None:
+        _req(g2v, torch.float64, "pos_emb.emb.weight")
+        if g2v.shape[0] < n or g2v.shape[1] != d:
+            raise ValueError("positional table too small")
+    out = torch.empty((b, n, d), dtype=F32, device=tok.device)
+    err = torch.zeros(1, dtype=torch.int32, device=tok.device)
+    check(lib.scm_embed_fwd(_p(tok), _p(emb), _p(g2v), b, n, d, v, _p(out), _p(err), _stream()), "scm_embed_fwd")
+    out._scm_err = err  # checked lazily by the caller (no sync here)
+    return out
+
+
+def embed_bwd(tok: torch.Tensor, dx: torch.Tensor, num_tokens: int, grad: torch.Tensor, accumulate: bool):
+    t = tok.numel()
+    d = dx.shape[-1]
+    ws = torch.empty(lib.scm_embed_bwd_ws_floats(t, d, num_tokens), dtype=F32, device=dx.device)
+    check(lib.scm_embed_bwd(_p(tok), _p(dx), t, d, num_tokens, _p(ws), _p(grad), int(accumulate), _stream()),
+          "scm_embed_bwd")
+
+
+# ----------------------------------------------------------------------------- layer norm
+def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    _req(x, F32, "x")
+    d = x.shape[-1]
+    t = x.numel() // d
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    mean = torch.empty(t, dtype=F32, device=x.device)
+    rstd = torch.empty(t, dtype=F32, device=x.device)
+    check(lib.scm_ln_fwd(_p(x), _p(gamma), _p(beta), t, d, _p(y), _p(mean), _p(rstd), _stream()), "scm_ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool):
+    _req(dy, F32, "dy")
+    d = x.shape[-1]
+    t = x.numel() // d
+    dx = torch.empty_like(x)
+    ws = torch.empty(lib.scm_ln_bwd_ws_floats(t, d), dtype=F32, device=x.device)
+    check(lib.scm_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), t, d, _p(dx), _p(ws), _p(dgamma),
+                         _p(dbeta), _p(dres_colsum), int(accumulate), _stream()), "scm_ln_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- linear products
+def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, *, out0: torch.Tensor, out1=None, bias=None, resid=None,
+            pre=None):
+    """out0[M,N] = a[M,K] @ w[N,K]^T with epilogue `epi`; a is bf16 or f32 (row-major, last dim contiguous)."""
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and w.dtype == BF16 and a.stride(1) == 1 and w.stride(1) == 1
+    check(lib.scm_gemm_nt(epi, int(a.dtype == F32), _p(a), a.stride(0), _p(w), w.stride(0), m, n, k,
+                          _p(out0), out0.stride(0), _p(out1), out1.stride(0) if out1 is not None else 0,
+                          _p(bias), _p(resid), resid.stride(0) if resid is not None else 0,
+                          _p(pre), pre.stride(0) if pre is not None else 0, _stream()), "scm_gemm_nt")
+    return out0
+
+
+def wgrad_slices(t: int, p: int) -> int:
+    """token slices so that (P/160) * slices workgroups fill the 256 CUs about twice"""
+    tiles = max(1, (t + 63) // 64)
+    return max(1, min(tiles, (512 * 160) // p))
+
+
+def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, trans: bool, accumulate: bool):
+    """grad (+)= pm^T qm  ([P,Q], or its transpose when trans); bias_grad (+)= column sums of pm."""
+    t, p = pm.shape
+    q = qm.shape[1]
+    s = wgrad_slices(t, p)
+    ws = torch.empty(lib.scm_wgrad_ws_floats(p, s), dtype=F32, device=pm.device)
+    check(lib.scm_wgrad(_p(pm), pm.stride(0), _p(qm), qm.stride(0), int(qm.dtype == F32), t, p, q, s, _p(ws),
+                        _p(grad), _p(bias_grad), int(trans), int(accumulate), _stream()), "scm_wgrad")
+
+
+# ----------------------------------------------------------------------------- FAVOR+ attention
+@dataclass
+class FavorSaved:
+    plan: FavorPlan
+    ctx: torch.Tensor     # [BH,288,64] bf16
+    z: torch.Tensor       # [BH,288]
+    sums: torch.Tensor    # [BH,80]
+    rowmax: torch.Tensor  # [BH*N]
+    den: torch.Tensor     # [BH*N]
+    kmax: torch.Tensor    # partial maxima
+    kmax_idx: torch.Tensor  # their positions
+
+
+def make_plan(b: int, h: int, n: int) -> FavorPlan:
+    plan = FavorPlan()
+    check(lib.scm_favor_make_plan(b, h, n, C.byref(plan)), "scm_favor_make_plan")
+    return plan
+
+
+def favor_fwd(q, k, v, omega_b, out) -> FavorSaved:
+    """q,k,v,out: bf16 [B,H,N,64] views (any b/h/n strides)."""
+    b, h, n, _ = q.shape
+    dev = q.device
+    plan = make_plan(b, h, n)
+    bh = b * h
+    ctx = torch.empty((bh, NB_FEATURES_PAD, DIM_HEAD), dtype=BF16, device=dev)
+    z = torch.empty((bh, NB_FEATURES_PAD), dtype=F32, device=dev)
+    sums = torch.empty((bh, 80), dtype=F32, device=dev)
+    rowmax = torch.empty(bh * n, dtype=F32, device=dev)
+    den = torch.empty(bh * n, dtype=F32, device=dev)
+    kmax = torch.empty(plan.kmax_chunks * bh, dtype=F32, device=dev)
+    kidx = torch.empty(plan.kmax_chunks * bh, dtype=torch.int64, device=dev)
+    ws = torch.empty(lib.scm_favor_ws_floats(C.byref(plan)), dtype=F32, device=dev)
+    check(lib.scm_favor_fwd(C.byref(plan), view4(q), view4(k), view4(v), _p(omega_b), view4(out), _p(ctx), _p(z),
+                            _p(sums), _p(rowmax), _p(den), _p(kmax), _p(kidx), _p(ws), _stream()), "scm_favor_fwd")
+    return FavorSaved(plan, ctx, z, sums, rowmax, den, kmax, kidx)
+
+
+def favor_bwd(q, k, v, o, dout, omega_b, sv: FavorSaved, dq, dk, dv):
+    dev = q.device
+    plan = sv.plan
+    bh = plan.B * plan.H
+    dctx = torch.empty_like(sv.ctx)
+    dz = torch.empty_like(sv.z)
+    dsums = torch.empty_like(sv.sums)
+    dden = torch.empty_like(sv.den)
+    ws = torch.empty(lib.scm_favor_ws_floats(C.byref(plan)), dtype=F32, device=dev)
+    check(lib.scm_favor_bwd(C.byref(plan), view4(q), view4(k), view4(v), view4(o), view4(dout), _p(omega_b),
+                            _p(sv.ctx), _p(sv.z), _p(sv.sums), _p(sv.rowmax), _p(sv.den), _p(sv.kmax),
+                            _p(sv.kmax_idx), view4(dq), view4(dk), view4(dv), _p(dctx), _p(dz), _p(dsums), _p(dden), _p(ws),
+                            _stream()), "scm_favor_bwd")
+
+
+# ----------------------------------------------------------------------------- final norm + head
+def head_fwd(x, gamma, beta, w, bias, relu: bool, want_enc: bool, want_out: bool):
+    _req(x, F32, "x")
+    d = x.shape[-1]
+    t = x.numel() // d
+    c = w.shape[0] if (w is not None and want_out) else 0
+    enc = torch.empty_like(x) if want_enc else None
+    out = torch.empty((*x.shape[:-1], c), dtype=F32, device=x.device) if c > 0 else None
+    mean = torch.empty(t, dtype=F32, device=x.device)
+    rstd = torch.empty(t, dtype=F32, device=x.device)
+    check(lib.scm_head_fwd(_p(x), _p(gamma), _p(beta), _p(w) if c else None, _p(bias) if c else None, t, d, c,
+                           int(relu), _p(enc), _p(out), _p(mean), _p(rstd), _stream()), "scm_head_fwd")
+    return enc, out, mean, rstd
+
+
+def head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, w, relu: bool, dgamma, dbeta, dw, db, accumulate: bool):
+    d = x.shape[-1]
+    t = x.numel() // d
+    c = w.shape[0] if (w is not None and dout is not None) else 0
+    dx = torch.empty_like(x)
+    ws = torch.empty(lib.scm_head_bwd_ws_floats(t, d, c), dtype=F32, device=x.device)
+    check(lib.scm_head_bwd(_p(dout), _p(denc), _p(out), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                           _p(w) if c else None, t, d, c, int(relu), _p(dx), _p(ws), _p(dgamma), _p(dbeta),
+                           _p(dw) if c else None, _p(db) if c else None, int(accumulate), _stream()), "scm_head_bwd")
+    return dx
