@@ -94,17 +94,22 @@ typedef struct {
 /* fills the chunk counts for the MI355X (256 CUs) */
 int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan /* host */);
 int64_t scm_favor_ws_floats(const scm_favor_plan* plan /* host */);
-/* Saved state of one forward call (caller-allocated):
- *   ctx_bf16 [B*H,288,64] bf16, z [B*H,288] f32, sums [B*H,80] f32, rowmax [B*H*N] f32, den [B*H*N] f32,
+/* out = attention output; out_centered = out - obar[b,h,:] where obar is the (k'-weighted) mean value vector
+ * of the head: kept for the backward, whose denominator path needs it at full relative precision.
+ * Saved state of one forward call (caller-allocated):
+ *   ctx_bf16 [B*H,288,64] bf16 (centred K'^T V), z [B*H,288] f32, sums [B*H,80] f32 (obar, sum z),
+ *   rowmax [B*H*N] f32, den [B*H*N] f32,
  *   kmax [kmax_chunks*B*H] f32 (partial maxima; their max is the key stabiliser of performer_pytorch.py:90),
  *   kmax_idx [kmax_chunks*B*H] i64 (where each partial maximum sits: (bh*N + n)*512 + feature). */
 int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, const void* omega_b,
-                  scm_view4 out, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
+                  scm_view4 out, scm_view4 out_centered, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
                   int64_t* kmax_idx, float* ws, void* stream);
 /* Backward of the above: dq, dk, dv from dout, including the gradient that autograd routes through both
- * stabilisers (per-token argmax for queries, the single global argmax for keys).  `o` is the forward output.
+ * stabilisers (per-token argmax for queries, the single global argmax for keys).  `o_centered` is the
+ * second forward output.
  * Scratch: dctx_bf16/dz/dsums shaped like ctx_bf16/z/sums, dden [B*H*N]. */
-int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, scm_view4 o, scm_view4 dout,
+int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, scm_view4 o_centered,
+                  scm_view4 dout,
                   const void* omega_b, const void* ctx_bf16, const float* z, const float* sums, const float* rowmax,
                   const float* den, const float* kmax, const int64_t* kmax_idx, scm_view4 dq, scm_view4 dk,
                   scm_view4 dv, void* dctx_bf16, float* dz, float* dsums, float* dden, float* ws, void* stream);

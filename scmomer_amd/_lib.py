@@ -42,7 +42,7 @@ SIGNATURES = {
     "scm_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, i32, i32, vp]),
     "scm_favor_make_plan": (i32, [i32, i32, i32, C.POINTER(FavorPlan)]),
     "scm_favor_ws_floats": (i64, [C.POINTER(FavorPlan)]),
-    "scm_favor_fwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, vp, View4, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "scm_favor_fwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, vp, View4, View4, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scm_favor_bwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, View4, View4, vp, vp, vp, vp, vp, vp, vp, vp,
                             View4, View4, View4, vp, vp, vp, vp, vp, vp]),
     "scm_head_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),

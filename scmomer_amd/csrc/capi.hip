@@ -164,10 +164,11 @@ static int plan_ok(const scm_favor_plan* p) {
 }
 
 int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, const void* omega_b,
-                  scm_view4 out, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
+                  scm_view4 out, scm_view4 out_centered, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
                   int64_t* kmax_idx, float* ws, void* stream) {
   SCM_REQ(plan_ok(plan), "scm_favor_fwd: bad plan");
-  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(out), "scm_favor_fwd: bad tensor view (null/unaligned)");
+  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(out) && view_ok(out_centered),
+          "scm_favor_fwd: bad tensor view (null/unaligned)");
   SCM_REQ(omega_b && ctx_bf16 && z && sums && rowmax && den && kmax && kmax_idx && ws, "scm_favor_fwd: null pointer");
   SCM_REQ(aligned16(omega_b) && aligned16(ctx_bf16), "scm_favor_fwd: unaligned pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -178,20 +179,21 @@ int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   c.stab = kmax; c.nstab = plan->kmax_chunks * B * H; c.den = nullptr; c.dden = nullptr;
   c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(0, c, B, plan->ctx_chunks, s), "favor_ctx");
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, ctx_bf16, z, sums, s), "favor_ctx_finalize");
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 0, nullptr, ctx_bf16, z, sums, s), "favor_ctx_finalize");
   ApplyArgs a{};
   a.x = cview(q); a.omega_b = (const bf16*)omega_b; a.Mb = (const bf16*)ctx_bf16; a.zf = z; a.sums = sums;
-  a.out0 = oview(out); a.rowmax_out = rowmax; a.den_out = den; a.H = H; a.N = N;
+  a.out0 = oview(out); a.out1 = oview(out_centered); a.rowmax_out = rowmax; a.den_out = den; a.H = H; a.N = N;
   SCM_HIP(favor_apply(0, a, B, plan->apply_chunks, s), "favor_apply");
   return 0;
 }
 
-int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, scm_view4 o, scm_view4 dout,
+int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, scm_view4 o_centered,
+                  scm_view4 dout,
                   const void* omega_b, const void* ctx_bf16, const float* z, const float* sums, const float* rowmax,
                   const float* den, const float* kmax, const int64_t* kmax_idx, scm_view4 dq, scm_view4 dk,
                   scm_view4 dv, void* dctx_bf16, float* dz, float* dsums, float* dden, float* ws, void* stream) {
   SCM_REQ(plan_ok(plan), "scm_favor_bwd: bad plan");
-  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(o) && view_ok(dout) && view_ok(dq) && view_ok(dk) &&
+  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(o_centered) && view_ok(dout) && view_ok(dq) && view_ok(dk) &&
               view_ok(dv), "scm_favor_bwd: bad tensor view (null/unaligned)");
   SCM_REQ(omega_b && ctx_bf16 && z && sums && rowmax && den && kmax && kmax_idx && dctx_bf16 && dz && dsums &&
               dden && ws, "scm_favor_bwd: null pointer");
@@ -199,7 +201,7 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   const int B = plan->B, H = plan->H, N = plan->N;
   // 1. query side: dq and dden (needs C, z of the forward)
   ApplyArgs a{};
-  a.x = cview(q); a.y = cview(dout); a.y2 = cview(o); a.omega_b = (const bf16*)omega_b; a.Mb = (const bf16*)ctx_bf16;
+  a.x = cview(q); a.y = cview(dout); a.y2 = cview(o_centered); a.omega_b = (const bf16*)omega_b; a.Mb = (const bf16*)ctx_bf16;
   a.zf = z; a.sums = sums; a.stab = rowmax; a.den_in = den; a.out0 = oview(dq); a.dden_out = dden; a.H = H; a.N = N;
   SCM_HIP(favor_apply(1, a, B, plan->apply_chunks, s), "favor_apply(dq)");
   // 2. dC, dz = sum over tokens of the query features against dO/den and dden
@@ -207,7 +209,8 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   c.x = cview(q); c.y = cview(dout); c.omega_b = (const bf16*)omega_b; c.stab = rowmax; c.nstab = 0; c.den = den;
   c.dden = dden; c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(1, c, B, plan->ctx_chunks, s), "favor_ctx(dC)");
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, dctx_bf16, dz, dsums, s), "favor_ctx_finalize(dC)");
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 1, sums, dctx_bf16, dz, dsums, s),
+          "favor_ctx_finalize(dC)");
   // 3. key side: dk, dv
   ApplyArgs g{};
   g.x = cview(k); g.y = cview(v); g.omega_b = (const bf16*)omega_b; g.Mb = (const bf16*)dctx_bf16; g.zf = dz;

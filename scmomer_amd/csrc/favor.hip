@@ -8,7 +8,11 @@
 //   C[m,:] = sum_n (Ek+eps) v_n     z[m] = sum_n (Ek+eps)
 //   o_n = ((Eq+eps) C) / ((Eq+eps) z)
 // The eps terms are carried analytically (column sums) so the MFMA operands are pure
-// exponentials, whose bf16 rounding is relative at any magnitude.
+// exponentials, whose bf16 rounding is relative at any magnitude.  The context is used CENTRED:
+// with obar = colsum(C)/sum(z), C' = C - z obar^T and o_n = obar + ((Eq+eps) C')_n / den_n.
+// When attention is near uniform every row of C/z is close to obar; centring keeps the bf16
+// rounding relative to the (small) deviations, in the forward and in the backward, where
+// dE'q = dnum C'^T - (dO . (o - obar)) z / den is otherwise a difference of nearly equal terms.
 //
 // Kernels
 //   favor_kmax          max of k.w over the whole local batch -> per-workgroup partial maxima
@@ -174,14 +178,11 @@ constexpr int CTX_BUF = 2 * CTX_TILE * 128 + 2 * CTX_TILE * 4;  // x image, y im
 template <int MODE>
 __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ysum_s = (float*)(smem + 2 * CTX_BUF);  // [64] then wsum at [64]; all LDS is dynamic
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int n_lo = blockIdx.x * a.chunk_len, n_hi = min(a.N, n_lo + a.chunk_len);
   const bool loader = tid < 512;
   const int lrow = tid >> 3, lch = tid & 7;
-
-  if (tid <= DH) ysum_s[tid] = 0.f;
 
   float gstab = 0.f;
   if (MODE == 0) gstab = reduce_partial_max(a.stab, a.nstab);
@@ -298,26 +299,36 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     for (int r = 0; r < 16; ++r) rec[(32 * w + acc_row(r, half)) * DH + 32 * dt + (l & 31)] = cacc[dt][r];
   const float zt = xhalf_sum(zacc);
   if (l < 32) rec[NFP * DH + 32 * w + l] = zt;
+  // fixed-order reduction of the loaders' column sums through the (now idle) tile buffers
+  float* red = (float*)smem;  // [64 rows][64 + 1]
   if (loader) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&ysum_s[8 * lch + j], ysum[j]);
-    if (MODE == 1 && lch == 0) atomicAdd(&ysum_s[DH], wsum);
+    for (int j = 0; j < 8; ++j) red[lrow * 65 + 8 * lch + j] = ysum[j];
+    if (lch == 0) red[lrow * 65 + 64] = wsum;
   }
   __syncthreads();
-  if (tid < DH) rec[NFP * DH + NFP + tid] = ysum_s[tid];
-  if (tid == 0) rec[NFP * DH + NFP + DH] = (MODE == 1) ? ysum_s[DH] : (float)max(0, n_hi - n_lo);
+  if (tid <= DH) {
+    float s = 0.f;
+    for (int r = 0; r < CTX_TILE; ++r) s += red[r * 65 + tid];
+    if (tid < DH) rec[NFP * DH + NFP + tid] = s;
+    else rec[NFP * DH + NFP + DH] = (MODE == 1) ? s : (float)max(0, n_hi - n_lo);
+  }
 }
 
-// Sum chunk partials, add the analytic eps terms, write:
-//   Mb  bf16 [bh][288][64]   M[m,d] = sum_c CE + eps * ysum[d]       (0 for padded features)
-//   zf  f32  [bh][288]       z[m]   = sum_c zE + eps * wsum
-//   sums f32 [bh][80]        sums[d] = sum_m M[m,d] ; sums[64] = sum_m z[m]
-__global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __restrict__ part, int nchunks,
+// Sum chunk partials, add the analytic eps terms.  With M = sum_c CE + eps * ysum, zz = sum_c zE + eps * wsum:
+//  mode 0 (forward context): z = zz, obar[d] = colsum(M)[d] / sum(z), writes the CENTRED context
+//      Mb[m,d] = bf16(M[m,d] - z[m] * obar[d]), zf = z, sums[0..63] = obar, sums[64] = sum(z).
+//  mode 1 (backward): Mb = bf16(M) = dC, sums[0..63] = colsum(dC), and, the partial z-sums having been
+//      taken against the centred denominator gradient, zf[m] = zz[m] - dC[m,:] . obar_fwd.
+__global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __restrict__ part, int nchunks, int mode,
+                                                                 const float* __restrict__ sums_fwd,
                                                                  bf16* __restrict__ Mb, float* __restrict__ zf,
                                                                  float* __restrict__ sums) {
   __shared__ float ysum[DH];
+  __shared__ float obar[DH];
   __shared__ float wsum;
   __shared__ float colp[4][DH];
+  __shared__ float zl[NFP];
   __shared__ float zp[256];
   const int tid = threadIdx.x, bh = blockIdx.x;
   const float* base = part + (long)bh * nchunks * CTX_PART;
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NFP + tid];
     ysum[tid] = s;
+    if (mode == 1) obar[tid] = sums_fwd[(long)bh * SUMS_STRIDE + tid];
   }
   if (tid == 64) {
     float s = 0.f;
@@ -332,32 +344,53 @@ __global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __
     wsum = s;
   }
   __syncthreads();
-  // thread -> column d = tid & 63, rows m = (tid >> 6) + 4*i
-  const int d = tid & 63, q = tid >> 6;
-  float csum = 0.f;
-  for (int m = q; m < NFP; m += 4) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + m * DH + d];
-    const float v = (m < NF) ? s + KEPS * ysum[d] : 0.f;
-    Mb[((long)bh * NFP + m) * DH + d] = (bf16)v;
-    csum += v;
-  }
-  colp[q][d] = csum;
   float zs = 0.f;
   for (int m = tid; m < NFP; m += 256) {
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + m];
     const float v = (m < NF) ? s + KEPS * wsum : 0.f;
-    zf[(long)bh * NFP + m] = v;
+    zl[m] = v;
     zs += v;
   }
   zp[tid] = zs;
-  __syncthreads();
-  if (tid < DH) sums[(long)bh * SUMS_STRIDE + tid] = colp[0][tid] + colp[1][tid] + colp[2][tid] + colp[3][tid];
-  if (tid == 0) {
+  // thread -> column d = tid & 63 (one wave per q), rows m = q + 4*i
+  const int d = tid & 63, q = tid >> 6;
+  float csum = 0.f;
+  for (int m = q; m < NF; m += 4) {
     float s = 0.f;
-    for (int i = 0; i < 256; ++i) s += zp[i];
-    sums[(long)bh * SUMS_STRIDE + DH] = s;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + m * DH + d];
+    csum += s + KEPS * ysum[d];
+  }
+  colp[q][d] = csum;
+  __syncthreads();
+  float zsum = 0.f;
+  if (mode == 0) {
+    for (int i = 0; i < 256; ++i) zsum += zp[i];
+    if (tid < DH) obar[tid] = (colp[0][tid] + colp[1][tid] + colp[2][tid] + colp[3][tid]) / zsum;
+    __syncthreads();
+  }
+  for (int m = q; m < NFP; m += 4) {
+    float v = 0.f;
+    if (m < NF) {
+      float s = 0.f;
+      for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + m * DH + d];
+      v = s + KEPS * ysum[d];
+    }
+    if (mode == 0) {
+      Mb[((long)bh * NFP + m) * DH + d] = (bf16)((m < NF) ? v - zl[m] * obar[d] : 0.f);
+    } else {
+      Mb[((long)bh * NFP + m) * DH + d] = (bf16)v;
+      const float dot = wave_sum(v * obar[d]);  // the 64 lanes of this wave hold row m
+      if (d == 0) zf[(long)bh * NFP + m] = (m < NF) ? zl[m] - dot : 0.f;
+    }
+  }
+  if (mode == 0) {
+    for (int m = tid; m < NFP; m += 256) zf[(long)bh * NFP + m] = zl[m];
+    if (tid < DH) sums[(long)bh * SUMS_STRIDE + tid] = obar[tid];
+    if (tid == 0) sums[(long)bh * SUMS_STRIDE + DH] = zsum;
+  } else {
+    if (tid < DH) sums[(long)bh * SUMS_STRIDE + tid] = colp[0][tid] + colp[1][tid] + colp[2][tid] + colp[3][tid];
+    if (tid == 0) sums[(long)bh * SUMS_STRIDE + DH] = 0.f;
   }
 }
 
@@ -389,7 +422,8 @@ SCM_DEV void stage_rows(float* stage, const f32x16 (&y)[2], float scale, const f
 // out[row][d] = stage[row][d] + stage[row][64] * corr_scale * xrow[d]
 // and, with omg != null, + stage[row][65] * Omega[(int)stage[row][66]][d] (Omega from its LDS image)
 SCM_DEV void store_rows(const float* stage, bf16* __restrict__ obase, long osn, const bf16* __restrict__ xbase,
-                        long xsn, float corr_scale, int n0, int n_hi, const char* omg = nullptr) {
+                        long xsn, float corr_scale, int n0, int n_hi, const char* omg = nullptr,
+                        const float* colbias = nullptr) {
   const int l = lane_id();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -399,6 +433,10 @@ SCM_DEV void store_rows(const float* stage, bf16* __restrict__ obase, long osn, 
       const f32x4 a = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch);
       const f32x4 b = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch + 4);
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      if (colbias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += colbias[8 * ch + j];
+      }
       if (xbase) {
         const float cs = stage[row * STAGE_PITCH + 64] * corr_scale;
         const bf16x8 xv = *(const bf16x8*)(xbase + (long)n * xsn + 8 * ch);
@@ -492,10 +530,14 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       }
       const float den = xhalf_sum(dsum) + KEPS * zsum;
       const float inv = 1.f / den;
-      stage_rows(stage, Y, inv, sm, KEPS);
+      // the context image is centred (its feature-sum is zero, so the eps term vanishes):
+      // Y / den = o - obar
+      stage_rows(stage, Y, inv, nullptr, 0.f);
       __builtin_amdgcn_wave_barrier();
+      bf16* ocb = a.out1.p + b * a.out1.sb + h * a.out1.sh;
+      store_rows(stage, ocb, a.out1.sn, nullptr, 0, 0.f, n0, n_hi);
       bf16* ob = a.out0.p + b * a.out0.sb + h * a.out0.sh;
-      store_rows(stage, ob, a.out0.sn, nullptr, 0, 0.f, n0, n_hi);
+      store_rows(stage, ob, a.out0.sn, nullptr, 0, 0.f, n0, n_hi, nullptr, sm);
       __builtin_amdgcn_wave_barrier();
       if (valid && l < 32) { a.rowmax_out[srow + n] = mx; a.den_out[srow + n] = den; }
     }
@@ -522,15 +564,12 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
         for (int j = 0; j < 8; ++j) dof[ks][j] = (bf16)((float)dof[ks][j] * inv);
       const float off = (HALF_C2 * norm2 + CNORM * rmx) * LOG2E;
       f32x16 Y[2] = {zero16(), zero16()};
-      float rs = 0.f;
+      float rs = 0.f, rsmax = 0.f;
       int jstar = 1 << 20;
 #pragma unroll 1
       for (int t = 0; t < NFT; ++t) {
         const f32x16 X = score_tile(omg, t, xf);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (feat_valid(t, r, half) && X[r] == rmx) jstar = min(jstar, 32 * t + acc_row(r, half));
-        // G[m,token] = C_t (32x64) * dnum^T (64x32) + z[m] * dden
+        // G[m,token] = C'_t (32x64) * dnum^T (64x32) + z[m] * dden   (centred context, centred dden)
         f32x16 G = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) G = mfma32(img_row_frag(mim, 32 * t, 16 * ks), dof[ks], G);
@@ -542,10 +581,16 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * g + i;
             float e = exp2_fast(X[r] * (CNORM * LOG2E) - off);
-            e = feat_valid(t, r, half) ? e : 0.f;
+            const bool fv = feat_valid(t, r, half);
+            e = fv ? e : 0.f;
             const float v = e * (G[r] + z4[i] * dden);
-            dA[r] = v;
             rs += v;
+            // The stabiliser routes -sum(dA) to the arg-max feature j*, so dA[j*] Omega[j*] cancels
+            // against it exactly: keep that (largest) element out of the bf16 product and apply the
+            // net coefficient -(sum(dA) - dA[j*]) in f32 at the write-back.
+            const bool ismax = fv && X[r] == rmx;
+            if (ismax) { jstar = min(jstar, 32 * t + acc_row(r, half)); rsmax += v; }
+            dA[r] = ismax ? 0.f : v;
           }
         }
 #pragma unroll
@@ -556,13 +601,15 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
             Y[dt] = mfma32(img_tr_frag<true>(omg, 32 * t + 16 * sk, 32 * dt), af, Y[dt]);
         }
       }
-      const float ddiag = -xhalf_sum(rs);
+      const float rs_all = xhalf_sum(rs);
+      const float ddiag = -rs_all;
+      const float stabc = -(rs_all - xhalf_sum(rsmax));
       jstar = min(jstar, __shfl_xor(jstar, 32));
       stage_rows(stage, Y, CNORM, nullptr, 0.f);
       if (l < 32) {
         stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
-        // stabiliser gradient: rowmax = S[n, j*]  =>  dq += c * ddiag * Omega[j*]
-        stage[(l & 31) * STAGE_PITCH + 65] = (jstar < NF) ? CNORM * ddiag : 0.f;
+        // stabiliser gradient: rowmax = S[n, j*]  =>  dq += -c * (sum(dA) - dA[j*]) * Omega[j*]
+        stage[(l & 31) * STAGE_PITCH + 65] = (jstar < NF) ? CNORM * stabc : 0.f;
         ((int*)stage)[(l & 31) * STAGE_PITCH + 66] = (jstar < NF) ? jstar : 0;
       }
       __builtin_amdgcn_wave_barrier();
@@ -678,9 +725,10 @@ hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, void* Mb, float* zf, float* sums,
-                              hipStream_t s) {
-  hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH), dim3(256), 0, s, part, nchunks, (bf16*)Mb, zf, sums);
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* sums_fwd, void* Mb,
+                              float* zf, float* sums, hipStream_t s) {
+  hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH), dim3(256), 0, s, part, nchunks, mode, sums_fwd, (bf16*)Mb,
+                     zf, sums);
   return hipGetLastError();
 }
 
@@ -691,9 +739,9 @@ hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s)
   const size_t lds = favor_apply_lds();
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)favor_apply_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)favor_apply_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)favor_apply_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)favor_apply_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)favor_apply_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)favor_apply_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(nchunks, B * a.H);

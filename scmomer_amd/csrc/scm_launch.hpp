@@ -35,16 +35,16 @@ struct CtxArgs {
 struct ApplyArgs {
   TensorBHND x;            // MODE 0,1: q ; MODE 2: k
   TensorBHND y;            // MODE 1: dO ; MODE 2: v
-  TensorBHND y2;           // MODE 1: o (saved forward output)
+  TensorBHND y2;           // MODE 1: o - obar (saved centred forward output)
   const bf16* omega_b;     // [288][64]
-  const bf16* Mb;          // [bh][288][64]  MODE 0,1: C ; MODE 2: dC
+  const bf16* Mb;          // [bh][288][64]  MODE 0,1: centred C ; MODE 2: dC
   const float* zf;         // [bh][288]      MODE 0,1: z ; MODE 2: dz
-  const float* sums;       // [bh][80]
+  const float* sums;       // [bh][80]       MODE 0: obar[64], sum(z) ; MODE 2: colsum(dC)
   const float* stab;       // MODE 1: rowmax [B*H*N] ; MODE 2: kmax partials
   int nstab;
   const float* den_in;     // MODE 1
   TensorBHND_out out0;     // MODE 0: o ; MODE 1: dq ; MODE 2: dk
-  TensorBHND_out out1;     // MODE 2: dv
+  TensorBHND_out out1;     // MODE 0: o - obar ; MODE 2: dv
   float* rowmax_out;       // MODE 0
   float* den_out;          // MODE 0
   float* dden_out;         // MODE 1
@@ -88,8 +88,8 @@ hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, in
 hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
                       const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s);
 hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s);
-hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, void* Mb, float* zf, float* sums,
-                              hipStream_t s);
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* sums_fwd, void* Mb,
+                              float* zf, float* sums, hipStream_t s);
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s);
 
 }  // namespace scm

@@ -165,8 +165,8 @@ def make_plan(b: int, h: int, n: int) -> FavorPlan:
     return plan
 
 
-def favor_fwd(q, k, v, omega_b, out) -> FavorSaved:
-    """q,k,v,out: bf16 [B,H,N,64] views (any b/h/n strides)."""
+def favor_fwd(q, k, v, omega_b, out, out_centered) -> FavorSaved:
+    """q,k,v,out,out_centered: bf16 [B,H,N,64] views (any b/h/n strides)."""
     b, h, n, _ = q.shape
     dev = q.device
     plan = make_plan(b, h, n)
@@ -179,12 +179,13 @@ def favor_fwd(q, k, v, omega_b, out) -> FavorSaved:
     kmax = torch.empty(plan.kmax_chunks * bh, dtype=F32, device=dev)
     kidx = torch.empty(plan.kmax_chunks * bh, dtype=torch.int64, device=dev)
     ws = torch.empty(lib.scm_favor_ws_floats(C.byref(plan)), dtype=F32, device=dev)
-    check(lib.scm_favor_fwd(C.byref(plan), view4(q), view4(k), view4(v), _p(omega_b), view4(out), _p(ctx), _p(z),
+    check(lib.scm_favor_fwd(C.byref(plan), view4(q), view4(k), view4(v), _p(omega_b), view4(out), view4(out_centered),
+                            _p(ctx), _p(z),
                             _p(sums), _p(rowmax), _p(den), _p(kmax), _p(kidx), _p(ws), _stream()), "scm_favor_fwd")
     return FavorSaved(plan, ctx, z, sums, rowmax, den, kmax, kidx)
 
 
-def favor_bwd(q, k, v, o, dout, omega_b, sv: FavorSaved, dq, dk, dv):
+def favor_bwd(q, k, v, o_centered, dout, omega_b, sv: FavorSaved, dq, dk, dv):
     dev = q.device
     plan = sv.plan
     bh = plan.B * plan.H
@@ -193,7 +194,7 @@ def favor_bwd(q, k, v, o, dout, omega_b, sv: FavorSaved, dq, dk, dv):
     dsums = torch.empty_like(sv.sums)
     dden = torch.empty_like(sv.den)
     ws = torch.empty(lib.scm_favor_ws_floats(C.byref(plan)), dtype=F32, device=dev)
-    check(lib.scm_favor_bwd(C.byref(plan), view4(q), view4(k), view4(v), view4(o), view4(dout), _p(omega_b),
+    check(lib.scm_favor_bwd(C.byref(plan), view4(q), view4(k), view4(v), view4(o_centered), view4(dout), _p(omega_b),
                             _p(sv.ctx), _p(sv.z), _p(sv.sums), _p(sv.rowmax), _p(sv.den), _p(sv.kmax),
                             _p(sv.kmax_idx), view4(dq), view4(dk), view4(dv), _p(dctx), _p(dz), _p(dsums), _p(dden), _p(ws),
                             _stream()), "scm_favor_bwd")

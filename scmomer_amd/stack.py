@@ -1,0 +1,463 @@
+"""Sequencing of the C-ABI kernels for the Performer stack, as autograd nodes.
+
+One ``torch.autograd.Function`` covers embedding -> layers -> final norm/head
+(PerformerLM.forward, performer_pytorch.py:599-636; SequentialSequence.forward,
+reversible.py:133-151).  Forward saves, per layer, the f32 residual inputs, the bf16 GEMM
+operands (LN outputs, fused qkv, attention output, FFN pre-activation and activation) and the
+small attention state; backward replays the layers in reverse with the data-gradient,
+weight-gradient and LayerNorm-backward kernels and honours ``needs_input_grad`` (frozen
+encoders stop early: s1_pretrain_rna.py:223-228, s2_pretrain_multimodal.py:234-241).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# --------------------------------------------------------------------------------------------
+# per-layer parameter handling
+# --------------------------------------------------------------------------------------------
+ATTN_KEYS = ("g1", "b1", "wq", "wk", "wv", "bq", "bk", "bv", "wo", "bo")
+FFN_KEYS = ("g2", "b2", "w1", "c1", "w2", "c2")
+
+
+def attn_params(pre_ln) -> Dict[str, Optional[torch.Tensor]]:
+    """PreLayerNorm(SelfAttention) -> tensors (biases of q/k/v may be None)."""
+    sa = pre_ln.fn
+    return {"g1": pre_ln.norm.weight, "b1": pre_ln.norm.bias, "wq": sa.to_q.weight, "wk": sa.to_k.weight,
+            "wv": sa.to_v.weight, "bq": sa.to_q.bias, "bk": sa.to_k.bias, "bv": sa.to_v.bias,
+            "wo": sa.to_out.weight, "bo": sa.to_out.bias, "omega": sa.fast_attention.projection_matrix,
+            "heads": sa.heads}
+
+
+def ffn_params(pre_ln) -> Dict[str, Optional[torch.Tensor]]:
+    """PreLayerNorm(Chunk(FeedForward)) -> tensors."""
+    ff = pre_ln.fn.fn if hasattr(pre_ln.fn, "fn") else pre_ln.fn
+    return {"g2": pre_ln.norm.weight, "b2": pre_ln.norm.bias, "w1": ff.w1.weight, "c1": ff.w1.bias,
+            "w2": ff.w2.weight, "c2": ff.w2.bias}
+
+
+def _ver(*ts) -> tuple:
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+
+
+class WeightCache:
+    """bf16 (and transposed bf16) copies of the f32 master weights, refreshed when a parameter's
+    storage or version counter changes (optimizer steps and load_state_dict bump the version)."""
+
+    def __init__(self):
+        self.store: Dict[Any, Tuple[tuple, dict]] = {}
+
+    def attn(self, key, p) -> dict:
+        ver = _ver(p["wq"], p["wk"], p["wv"], p["wo"], p["omega"], p["bq"], p["bk"], p["bv"])
+        hit = self.store.get(("a", key))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            wqkv = torch.cat([p["wq"], p["wk"], p["wv"]], 0).to(F32).contiguous()
+            wqkv_b, wqkv_t = ops.cast_weight(wqkv)
+            wo_b, wo_t = ops.cast_weight(p["wo"].detach().to(F32).contiguous())
+            omega_b = ops.prep_omega(p["omega"].detach().to(F32).contiguous())
+            bqkv = None
+            if p["bq"] is not None:
+                bqkv = torch.cat([p["bq"], p["bk"], p["bv"]], 0).to(F32).contiguous()
+        out = {"wqkv": wqkv_b, "wqkv_t": wqkv_t, "wo": wo_b, "wo_t": wo_t, "omega_b": omega_b, "bqkv": bqkv}
+        self.store[("a", key)] = (ver, out)
+        return out
+
+    def ffn(self, key, p) -> dict:
+        ver = _ver(p["w1"], p["w2"])
+        hit = self.store.get(("f", key))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            w1_b, w1_t = ops.cast_weight(p["w1"].detach().to(F32).contiguous())
+            w2_b, w2_t = ops.cast_weight(p["w2"].detach().to(F32).contiguous())
+        out = {"w1": w1_b, "w1_t": w1_t, "w2": w2_b, "w2_t": w2_t}
+        self.store[("f", key)] = (ver, out)
+        return out
+
+
+def _cache_of(owner) -> WeightCache:
+    c = owner.__dict__.get("_scm_wcache")
+    if c is None:
+        c = WeightCache()
+        owner.__dict__["_scm_wcache"] = c
+    return c
+
+
+# --------------------------------------------------------------------------------------------
+# branch forward / backward (shared by the fused stack and the stand-alone modules)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class AttnTape:
+    x: Optional[torch.Tensor]      # f32 [T,D] input of the LayerNorm (None when ln=False)
+    h: torch.Tensor                # bf16 [T,D] GEMM operand
+    mean: Optional[torch.Tensor]
+    rstd: Optional[torch.Tensor]
+    qkv: torch.Tensor              # bf16 [B,N,3,H,64]
+    o: torch.Tensor                # bf16 [B,N,H,64]
+    oc: torch.Tensor               # bf16 [B,N,H,64] output minus the per-head mean value vector
+    saved: Any
+    shape: tuple
+
+
+def _qkv_views(qkv5):
+    return tuple(qkv5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+
+
+def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool):
+    """x: f32 [B,N,D].  Returns (y f32 [B,N,D] = resid + to_out(attn(LN(x))) + bias, tape)."""
+    b, n, d = x.shape
+    t = b * n
+    heads = p["heads"]
+    inner = heads * ops.DIM_HEAD
+    x2 = x.reshape(t, d)
+    if ln:
+        h, mean, rstd = ops.ln_fwd(x2, p["g1"], p["b1"])
+    else:
+        h, mean, rstd = x2.to(BF16), None, None
+    qkv = torch.empty((t, 3 * inner), dtype=BF16, device=x.device)
+    if w["bqkv"] is not None:
+        ops.gemm_nt(ops.EPI_BF16_BIAS, h, w["wqkv"], out0=qkv, bias=w["bqkv"])
+    else:
+        ops.gemm_nt(ops.EPI_BF16, h, w["wqkv"], out0=qkv)
+    qkv5 = qkv.view(b, n, 3, heads, ops.DIM_HEAD)
+    q, k, v = _qkv_views(qkv5)
+    o = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device)
+    oc = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device)
+    saved = ops.favor_fwd(q, k, v, w["omega_b"], o.permute(0, 2, 1, 3), oc.permute(0, 2, 1, 3))
+    y = torch.empty((t, d), dtype=F32, device=x.device)
+    ops.gemm_nt(ops.EPI_F32_BIAS_RES, o.view(t, inner), w["wo"], out0=y, bias=p["bo"],
+                resid=resid.reshape(t, d) if resid is not None else None)
+    tape = AttnTape(x2 if ln else None, h, mean, rstd, qkv5, o, oc, saved, (b, n, d)) if save else None
+    return y.view(b, n, d), tape
+
+
+def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
+             dres: Optional[torch.Tensor], need_dx: bool):
+    """dy: f32 [T,D] gradient of the branch output.  Returns (dx f32 [T,D] or None, grads dict).
+    With ln: dx = dres + LN'(dh); grads['bo'] is taken from column sums of dy inside the LN kernel."""
+    b, n, d = tp.shape
+    t = b * n
+    heads = p["heads"]
+    inner = heads * ops.DIM_HEAD
+    dev = dy.device
+    g: Dict[str, torch.Tensor] = {}
+    if need["wo"]:
+        g["wo"] = torch.empty((d, inner), dtype=F32, device=dev)
+        ops.wgrad(tp.o.view(t, inner), dy, g["wo"], None, True, False)
+    need_qkv_w = need["wq"] or need["wk"] or need["wv"] or need["bq"]
+    need_dh = need_dx or (ln and (need["g1"] or need["b1"]))
+    if need_qkv_w or need_dh:
+        do = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=dev)
+        ops.gemm_nt(ops.EPI_BF16, dy, w["wo_t"], out0=do.view(t, inner))
+        dqkv = torch.empty((b, n, 3, heads, ops.DIM_HEAD), dtype=BF16, device=dev)
+        q, k, v = _qkv_views(tp.qkv)
+        dq, dk, dv = _qkv_views(dqkv)
+        ops.favor_bwd(q, k, v, tp.oc.permute(0, 2, 1, 3), do.permute(0, 2, 1, 3), w["omega_b"], tp.saved, dq, dk, dv)
+        dqkv2 = dqkv.view(t, 3 * inner)
+        if need_qkv_w:
+            gw = torch.empty((3 * inner, d), dtype=F32, device=dev)
+            gb = torch.empty(3 * inner, dtype=F32, device=dev) if w["bqkv"] is not None else None
+            ops.wgrad(dqkv2, tp.h, gw, gb, False, False)
+            g["wq"], g["wk"], g["wv"] = gw[:inner], gw[inner:2 * inner], gw[2 * inner:]
+            if gb is not None:
+                g["bq"], g["bk"], g["bv"] = gb[:inner], gb[inner:2 * inner], gb[2 * inner:]
+    dx = None
+    if need_dh:
+        dh = torch.empty((t, d), dtype=F32, device=dev)
+        ops.gemm_nt(ops.EPI_F32, dqkv2, w["wqkv_t"], out0=dh)
+        if ln:
+            g["g1"] = torch.empty(d, dtype=F32, device=dev)
+            g["b1"] = torch.empty(d, dtype=F32, device=dev)
+            g["bo"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
+            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g1"], dres, g["g1"], g["b1"], g["bo"], False)
+        else:
+            dx = dh
+    if need["bo"] and g.get("bo") is None:
+        g["bo"] = dy.sum(0)
+    return dx, g
+
+
+@dataclass
+class FfnTape:
+    x: Optional[torch.Tensor]
+    h: torch.Tensor
+    mean: Optional[torch.Tensor]
+    rstd: Optional[torch.Tensor]
+    pre: torch.Tensor
+    act: torch.Tensor
+    shape: tuple
+
+
+def ffn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool):
+    """y = resid + w2(gelu(w1(LN(x)) + c1)) + c2"""
+    b, n, d = x.shape
+    t = b * n
+    f = p["w1"].shape[0]
+    x2 = x.reshape(t, d)
+    if ln:
+        h, mean, rstd = ops.ln_fwd(x2, p["g2"], p["b2"])
+    else:
+        h, mean, rstd = x2.to(BF16), None, None
+    pre = torch.empty((t, f), dtype=BF16, device=x.device)
+    act = torch.empty((t, f), dtype=BF16, device=x.device)
+    ops.gemm_nt(ops.EPI_GELU_DUAL, h, w["w1"], out0=pre, out1=act, bias=p["c1"])
+    y = torch.empty((t, d), dtype=F32, device=x.device)
+    ops.gemm_nt(ops.EPI_F32_BIAS_RES, act, w["w2"], out0=y, bias=p["c2"],
+                resid=resid.reshape(t, d) if resid is not None else None)
+    tape = FfnTape(x2 if ln else None, h, mean, rstd, pre, act, (b, n, d)) if save else None
+    return y.view(b, n, d), tape
+
+
+def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
+            dres: Optional[torch.Tensor], need_dx: bool):
+    b, n, d = tp.shape
+    t = b * n
+    f = p["w1"].shape[0]
+    dev = dy.device
+    g: Dict[str, torch.Tensor] = {}
+    if need["w2"]:
+        g["w2"] = torch.empty((d, f), dtype=F32, device=dev)
+        ops.wgrad(tp.act, dy, g["w2"], None, True, False)
+    need_dh = need_dx or (ln and (need["g2"] or need["b2"]))
+    if need["w1"] or need["c1"] or need_dh:
+        dpre = torch.empty((t, f), dtype=BF16, device=dev)
+        ops.gemm_nt(ops.EPI_DGELU, dy, w["w2_t"], out0=dpre, pre=tp.pre)
+        if need["w1"] or need["c1"]:
+            g["w1"] = torch.empty((f, d), dtype=F32, device=dev)
+            g["c1"] = torch.empty(f, dtype=F32, device=dev)
+            ops.wgrad(dpre, tp.h, g["w1"], g["c1"], False, False)
+    dx = None
+    if need_dh:
+        dh = torch.empty((t, d), dtype=F32, device=dev)
+        ops.gemm_nt(ops.EPI_F32, dpre, w["w1_t"], out0=dh)
+        if ln:
+            g["g2"] = torch.empty(d, dtype=F32, device=dev)
+            g["b2"] = torch.empty(d, dtype=F32, device=dev)
+            g["c2"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
+            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g2"], dres, g["g2"], g["b2"], g["c2"], False)
+        else:
+            dx = dh
+    if need["c2"] and g.get("c2") is None:
+        g["c2"] = dy.sum(0)
+    return dx, g
+
+
+# --------------------------------------------------------------------------------------------
+# the fused stack
+# --------------------------------------------------------------------------------------------
+@dataclass
+class StackSpec:
+    layers: List[Tuple[dict, dict]]          # (attn_params, ffn_params) per layer
+    cache: WeightCache
+    names: List[Tuple[int, str]]             # flat differentiable-parameter order: (layer or -1/-2, key)
+    token_emb: Optional[torch.Tensor] = None
+    pos_table: Optional[torch.Tensor] = None
+    norm_w: Optional[torch.Tensor] = None
+    norm_b: Optional[torch.Tensor] = None
+    head_w: Optional[torch.Tensor] = None    # [C, D]
+    head_b: Optional[torch.Tensor] = None
+    head_relu: bool = False
+    head_out_shape: Optional[str] = None     # 'linear' | 'conv' | None (encodings only)
+    save: bool = True
+
+
+def _flat_params(spec: StackSpec) -> List[torch.Tensor]:
+    out = []
+    for li, key in spec.names:
+        if li == -1:
+            out.append(spec.token_emb)
+        elif li == -2:
+            out.append({"norm_w": spec.norm_w, "norm_b": spec.norm_b, "head_w": spec.head_w,
+                        "head_b": spec.head_b}[key])
+        else:
+            a, f = spec.layers[li]
+            out.append(a[key] if key in a else f[key])
+    return out
+
+
+class _StackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec: StackSpec, inp: torch.Tensor, *params):
+        if not inp.is_cuda:
+            raise RuntimeError("scmomer_amd runs on the MI355X kernels only: move the model and inputs to the GPU")
+        tapes = []
+        if spec.token_emb is not None:
+            tokens = inp
+            x = ops.embed_fwd(tokens.contiguous(), spec.token_emb.detach(), spec.pos_table)
+            ctx.embed_err = x._scm_err
+        else:
+            tokens = None
+            x = inp.to(F32).contiguous()
+        for li, (ap, fp) in enumerate(spec.layers):
+            aw = spec.cache.attn(li, ap)
+            fw = spec.cache.ffn(li, fp)
+            x1, at = attn_fwd(x, ap, aw, ln=True, resid=x, save=spec.save)
+            x2, ft = ffn_fwd(x1, fp, fw, ln=True, resid=x1, save=spec.save)
+            tapes.append((at, ft))
+            x = x2
+        ctx.spec, ctx.tapes, ctx.tokens = spec, tapes, tokens
+        if spec.norm_w is None:
+            ctx.head = None
+            return x
+        want_out = spec.head_out_shape is not None
+        enc, out, mean, rstd = ops.head_fwd(x, spec.norm_w, spec.norm_b, spec.head_w if want_out else None,
+                                            spec.head_b if want_out else None, spec.head_relu, not want_out,
+                                            want_out)
+        ctx.head = (x, mean, rstd, out) if spec.save else None
+        if not want_out:
+            return enc
+        if spec.head_out_shape == "conv":
+            return out.view(out.shape[0], -1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        spec: StackSpec = ctx.spec
+        if not spec.save:
+            raise RuntimeError("backward through a stack that was run without saving activations")
+        needs = ctx.needs_input_grad
+        need_p = {nm: needs[2 + i] for i, nm in enumerate(spec.names)}
+        grads: Dict[Tuple[int, str], torch.Tensor] = {}
+        nl = len(spec.layers)
+        # lowest layer whose parameters (or whose input) still need a gradient
+        need_inp = needs[1] or need_p.get((-1, "token_emb"), False)
+        first = nl
+        for li in range(nl):
+            if any(need_p.get((li, k), False) for k in ATTN_KEYS + FFN_KEYS):
+                first = li
+                break
+        if need_inp:
+            first = 0
+        dout = dout.contiguous()
+        if ctx.head is not None:
+            x, mean, rstd, out = ctx.head
+            t, d = x.numel() // x.shape[-1], x.shape[-1]
+            want_out = spec.head_out_shape is not None
+            dev = x.device
+            gg = torch.empty(d, dtype=F32, device=dev)
+            gb = torch.empty(d, dtype=F32, device=dev)
+            gw = torch.empty_like(spec.head_w) if want_out else None
+            gbias = torch.empty_like(spec.head_b) if want_out else None
+            dx = ops.head_bwd(dout.to(F32).reshape(t, -1) if want_out else None,
+                              None if want_out else dout.to(F32).reshape(t, d),
+                              out, x, mean, rstd, spec.norm_w, spec.norm_b, spec.head_w if want_out else None,
+                              spec.head_relu, gg, gb, gw.view(-1, d) if want_out else None,
+                              gbias.view(-1) if want_out else None, False)
+            dx = dx.reshape(t, d)
+            grads[(-2, "norm_w")], grads[(-2, "norm_b")] = gg, gb
+            if want_out:
+                grads[(-2, "head_w")], grads[(-2, "head_b")] = gw, gbias
+        else:
+            dx = dout.to(F32).reshape(-1, dout.shape[-1])
+        for li in range(nl - 1, first - 1, -1):
+            ap, fp = spec.layers[li]
+            aw, fw = spec.cache.attn(li, ap), spec.cache.ffn(li, fp)
+            at, ft = ctx.tapes[li]
+            lowest = li == first and not need_inp
+            nf = {k: need_p.get((li, k), False) for k in FFN_KEYS}
+            na = {k: need_p.get((li, k), False) for k in ATTN_KEYS}
+            attn_needs_any = any(na.values())
+            dx1, gf = ffn_bwd(dx, ft, fp, fw, nf, ln=True, dres=dx, need_dx=(not lowest) or attn_needs_any)
+            for k, v in gf.items():
+                if v is not None:
+                    grads[(li, k)] = v
+            if dx1 is None:
+                break
+            dx0, ga = attn_bwd(dx1, at, ap, aw, na, ln=True, dres=dx1, need_dx=not lowest)
+            for k, v in ga.items():
+                if v is not None:
+                    grads[(li, k)] = v
+            dx = dx0
+        d_inp = None
+        if first == 0 and need_inp and dx is not None:
+            if ctx.tokens is not None:
+                if need_p.get((-1, "token_emb"), False):
+                    ge = torch.empty_like(spec.token_emb)
+                    ops.embed_bwd(ctx.tokens.contiguous(), dx, spec.token_emb.shape[0], ge, False)
+                    grads[(-1, "token_emb")] = ge
+            else:
+                d_inp = dx.view(ctx.tapes[0][0].shape) if nl else dx
+        out_grads = []
+        for i, nm in enumerate(spec.names):
+            gval = grads.get(nm) if needs[2 + i] else None
+            out_grads.append(gval)
+        ctx.tapes = None
+        return (None, d_inp, *out_grads)
+
+
+def _build_spec(owner, layer_list, *, save: bool) -> StackSpec:
+    layers = [(attn_params(f), ffn_params(g)) for f, g in layer_list]
+    names: List[Tuple[int, str]] = []
+    for li, (a, f) in enumerate(layers):
+        for k in ATTN_KEYS:
+            if a[k] is not None:
+                names.append((li, k))
+        for k in FFN_KEYS:
+            names.append((li, k))
+    return StackSpec(layers=layers, cache=_cache_of(owner), names=names, save=save)
+
+
+def _head_kind(to_out, dim: int):
+    """'linear' for nn.Linear(dim, C<=8); 'conv' for the rna_encoder.py Identity head (1 x dim conv + ReLU)."""
+    if isinstance(to_out, nn.Linear) and to_out.in_features == dim and to_out.out_features <= 8 \
+            and to_out.bias is not None:
+        return "linear"
+    conv = getattr(to_out, "conv1", None)
+    if isinstance(conv, nn.Conv2d) and tuple(conv.weight.shape) == (1, 1, 1, dim) and conv.bias is not None \
+            and isinstance(getattr(to_out, "act", None), nn.ReLU):
+        return "conv"
+    return None
+
+
+def run_model(model, tokens: torch.Tensor, return_encodings: bool):
+    """PerformerLM.forward on the fused stack."""
+    if tokens.dtype != torch.int64:
+        tokens = tokens.long()
+    dim = model.token_emb.weight.shape[1]
+    grad_on = torch.is_grad_enabled()
+    spec = _build_spec(model, model.performer.net.layers, save=grad_on)
+    spec.token_emb = model.token_emb.weight
+    spec.names.insert(0, (-1, "token_emb"))
+    pos = getattr(model.pos_emb, "emb", None)
+    spec.pos_table = pos.weight.detach() if pos is not None else None
+    spec.norm_w, spec.norm_b = model.norm.weight, model.norm.bias
+    spec.names += [(-2, "norm_w"), (-2, "norm_b")]
+    kind = None if (return_encodings or model.to_out is None) else _head_kind(model.to_out, dim)
+    post = None
+    if kind == "linear":
+        spec.head_w, spec.head_b, spec.head_out_shape = model.to_out.weight, model.to_out.bias, "linear"
+        spec.names += [(-2, "head_w"), (-2, "head_b")]
+    elif kind == "conv":
+        spec.head_w, spec.head_b = model.to_out.conv1.weight, model.to_out.conv1.bias
+        spec.head_relu, spec.head_out_shape = True, "conv"
+        spec.names += [(-2, "head_w"), (-2, "head_b")]
+    elif not return_encodings:
+        post = model.to_out  # unknown head module: encodings from the kernels, head in torch
+    params = _flat_params(spec)
+    spec.save = grad_on and (any(p.requires_grad for p in params))
+    out = _StackFn.apply(spec, tokens, *params)
+    if post is not None:
+        return post(out)
+    if model.to_out is None and not return_encodings:
+        return out @ model.token_emb.weight.t()
+    return out
+
+
+def run_layers(performer, x: torch.Tensor):
+    """Performer.forward / SequentialSequence.forward on an already-embedded f32 [B,N,D] input."""
+    grad_on = torch.is_grad_enabled()
+    spec = _build_spec(performer, performer.net.layers, save=grad_on)
+    params = _flat_params(spec)
+    spec.save = grad_on and (x.requires_grad or any(p.requires_grad for p in params))
+    return _StackFn.apply(spec, x, *params)

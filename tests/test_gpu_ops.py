@@ -202,9 +202,10 @@ def _favor_case(ops, b, h, n, scale, seed):
     qd, kd, vd = (buf[:, :, i].permute(0, 2, 1, 3) for i in range(3))
     out = torch.zeros((b, n, h, 64), dtype=torch.bfloat16, device=DEV)
     outv = out.permute(0, 2, 1, 3)
+    outc = torch.zeros((b, n, h, 64), dtype=torch.bfloat16, device=DEV).permute(0, 2, 1, 3)
     omb = ops.prep_omega(omega.to(DEV))
-    saved = ops.favor_fwd(qd, kd, vd, omb, outv)
-    return dict(q=qd, k=kd, v=vd, out=outv, omb=omb, saved=saved, o64=o64, leaves=(q64, k64, v64), cot=cot,
+    saved = ops.favor_fwd(qd, kd, vd, omb, outv, outc)
+    return dict(q=qd, k=kd, v=vd, out=outv, outc=outc, omb=omb, saved=saved, o64=o64, leaves=(q64, k64, v64), cot=cot,
                 om16=om16)
 
 
@@ -231,7 +232,7 @@ def test_favor_backward(ops, b, h, n, scale):
     dout = c["cot"].permute(0, 2, 1, 3).contiguous().to(torch.bfloat16).to(DEV).permute(0, 2, 1, 3)
     dbuf = torch.zeros((b, n, 3, h, 64), dtype=torch.bfloat16, device=DEV)
     dq, dk, dv = (dbuf[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    ops.favor_bwd(c["q"], c["k"], c["v"], c["out"], dout, c["omb"], c["saved"], dq, dk, dv)
+    ops.favor_bwd(c["q"], c["k"], c["v"], c["outc"], dout, c["omb"], c["saved"], dq, dk, dv)
     # Gradient tolerances.  dq and dk are differences of two bf16-rounded products
     # (numerator path minus denominator path) that cancel almost completely when the attention
     # is near uniform, so their error is bounded against the magnitude of the cancelling term
