@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""S1 RNA masked-autoencoding pretrain micro-step benchmark (BASELINE.json config 2/3).
+
+One step = mask 15 % of the expressed genes of a 3-cell batch (s1_pretrain_rna.py:290), run the
+Performer RNA encoder forward (16,906 gene tokens, depth 6, dim 200, 10 heads, 266 features),
+cross-entropy with ignore_index, backward; every `--grad-acc` steps the gradients are synchronised
+(DDP over RCCL when --gpus > 1), clipped and applied with Adam, exactly as the reference's loop
+(s1_pretrain_rna.py:294-305).  Cells are sharded across ranks; per-GPU work is fixed (weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel, timed with HIP events on
+its launch stream inside the timed region; `cpu_baseline` is the CPU oracle (a port of the
+reference path, validated against it) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_GENES = 16906
+BATCH = 3
+FLOP_FWD_BWD_PER_CELL = 853.50e9   # algorithmic GEMM-term FLOPs, forward+backward, one cell
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA
+DOMINANT_KERNEL = os.environ.get("SCM_BENCH_TRACE_KERNEL", "favor_apply_bwd_k")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grad-acc", type=int, default=5, help="micro-steps per optimizer step (README uses 5)")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-all", action="store_true", help="time every kernel (per-kernel table to stderr)")
+    ap.add_argument("--eager", action="store_true", help="drive every launch from Python instead of a HIP graph")
+    return ap.parse_args()
+
+
+def build_model(device):
+    import scmomer_amd as S
+    torch.manual_seed(2024)            # identical random-init replica on every rank
+    model = S.PerformerLM(num_tokens=7, dim=200, depth=6, max_seq_len=N_GENES, heads=10, local_attn_heads=0,
+                          g2v_position_emb=True)
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():              # synthetic gene2vec table (float64, last row zero as in the reference)
+        model.pos_emb.emb.weight[:N_GENES] = torch.randn((N_GENES, 200), generator=gen, dtype=torch.float64)
+    model.fix_projection_matrices_()   # feature redraw disabled, as BASELINE.json prescribes
+    return model.to(device)
+
+
+def cpu_baseline():
+    """CPU oracle, B=1 forward+backward with the CE loss at the full 16,906 tokens, once, after a small
+    warm-up call that pages the math libraries in."""
+    from oracle import performer_oracle as O
+    import numpy as np
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    p = O.make_params(2024, depth=6, max_seq_len=N_GENES)
+    leaves = {k: v.clone().requires_grad_() for k, v in p.items()
+              if v.dtype == torch.float32 and not k.endswith("projection_matrix")}
+    pp = dict(p)
+    pp.update(leaves)
+    cells = O.synthetic_cells(2024, 1, N_GENES)
+    tokens = torch.from_numpy(np.minimum(cells, 5).astype(np.int64))
+    labels = tokens.clone()
+    labels[torch.rand(tokens.shape) > 0.15] = 6
+    small = tokens[:, :2048]
+    O.masked_ce_loss(O.performer_lm_forward(small, pp, depth=6, heads=10), labels[:, :2048], 6).backward()
+    t0 = time.perf_counter()
+    loss = O.masked_ce_loss(O.performer_lm_forward(tokens, pp, depth=6, heads=10), labels, 6)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "cells/s", "cores": threads, "kind": "port",
+            "sample": "1 cell (B=1), forward+backward+CE at 16906 tokens, fp32 torch-CPU oracle, one timed pass "
+                      f"({dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the kernels have no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+
+    from scmomer_amd import ops, s1, stack
+    torch.manual_seed(2024 + rank)
+    model = build_model(device)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=6, reduction="mean")
+    for p in params:                       # static gradient buffers: micro-steps accumulate into them
+        p.grad = torch.zeros_like(p)
+
+    # each rank owns its own shard of synthetic cells (resident in HBM before timing starts)
+    n_batches = 4
+    data = [s1.synthetic_tokens(1000 * rank + i, args.batch, N_GENES, device) for i in range(n_batches)]
+    static_tok = data[0].clone()
+    static_loss = torch.zeros((), device=device)
+
+    def micro_step():
+        """mask -> encoder forward -> CE -> backward (gradients accumulate), s1_pretrain_rna.py:290-302"""
+        masked, labels = s1.data_mask(static_tok, 0.15, 0.9, 6, 6)
+        loss = loss_fn(model(masked).transpose(1, 2), labels) / args.grad_acc
+        loss.backward()
+        static_loss.copy_(loss.detach())
+
+    def sync_step():
+        """every grad_acc micro-steps: average gradients over ranks (what DDP's reducer does on the sync
+        step, s1_pretrain_rna.py:299-305), clip, Adam, zero"""
+        if world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+            flat.div_(world)
+            off = 0
+            for p in params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        torch.nn.utils.clip_grad_norm_(params, int(1e2))
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+
+    # The micro-step is launch-bound when driven from Python (about 300 kernel launches), so it is captured
+    # once into a HIP graph and replayed; the bf16 weight copies are refreshed inside the graph.
+    graph = None
+    if not args.eager:
+        stack.WeightCache.enabled = False
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                micro_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            micro_step()
+        opt.zero_grad(set_to_none=False)
+
+    def step(i):
+        static_tok.copy_(data[i % n_batches])
+        if graph is not None:
+            graph.replay()
+        else:
+            micro_step()
+        if (i + 1) % args.grad_acc == 0:
+            sync_step()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(static_loss.item()) * args.grad_acc
+
+    # Per-kernel durations: HIP events on the launch stream around each launch of the traced kernel, taken on
+    # a few eager micro-steps right after the timed region (event pairs cannot be read back from inside a
+    # replayed graph; the kernels and their inputs are the same).
+    ops.trace_collect()
+    ops.trace_enable("all" if args.trace_all else DOMINANT_KERNEL)
+    for i in range(3):
+        static_tok.copy_(data[i % n_batches])
+        micro_step()
+    torch.cuda.synchronize()
+    ops.trace_enable(None)
+    trace = ops.trace_collect()
+
+    if rank == 0:
+        cells = world * args.batch * args.steps
+        value = cells / dt
+        ms, fl, cnt = trace.get(DOMINANT_KERNEL, (0.0, 0.0, 0))
+        roof = None
+        if cnt:
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                    "avg_launch_ms": ms / cnt, "launches": cnt,
+                    "whole_step_tflops": value / world * FLOP_FWD_BWD_PER_CELL / 1e12,
+                    "whole_step_frac": value / world * FLOP_FWD_BWD_PER_CELL / 1e12 / PEAK_BF16_TFLOPS}
+        if args.trace_all:
+            tot = sum(v[0] for v in trace.values())
+            for k, (m_, f_, c_) in sorted(trace.items(), key=lambda kv: -kv[1][0]):
+                print(f"  {k:22s} {m_:9.2f} ms {100 * m_ / tot:5.1f}%  launches {c_:5d}  "
+                      f"{(f_ / (m_ * 1e-3) / 1e12 if m_ > 0 else 0):8.1f} TFLOP/s", file=sys.stderr)
+        base = None
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_baseline()
+        out = {"metric": "cells/sec, Performer RNA encoder fwd+bwd (16.9k genes)", "value": value, "unit": "cells/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic",
+               "config": {"workload": "S1 RNA masked-autoencoding pretrain micro-step (mask_prob 0.15): mask + "
+                                      "Performer encoder fwd + CE + bwd; clip + Adam every grad_acc steps",
+                          "cells_per_gpu_per_step": args.batch, "gene_tokens": N_GENES, "depth": 6, "dim": 200,
+                          "heads": 10, "nb_features": 266, "grad_acc": args.grad_acc,
+                          "parallelism": f"dp{world}", "feature_redraw": "disabled",
+                          "launch": "eager" if args.eager else "hip-graph replay of the micro-step"},
+               "final_loss": final_loss, "roofline": roof, "cpu_baseline": base}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,10 @@ SIGNATURES = {
     "scm_favor_fwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, vp, View4, View4, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scm_favor_bwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, View4, View4, vp, vp, vp, vp, vp, vp, vp, vp,
                             View4, View4, View4, vp, vp, vp, vp, vp, vp]),
+    "scm_trace_kernel_count": (i32, []),
+    "scm_trace_kernel_name": (C.c_char_p, [i32]),
+    "scm_trace_enable": (i32, [i32]),
+    "scm_trace_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "scm_head_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
     "scm_head_bwd_ws_floats": (i64, [i64, i32, i32]),
     "scm_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),

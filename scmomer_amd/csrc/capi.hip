@@ -5,6 +5,7 @@
 
 #include <stdio.h>
 #include <stdarg.h>
+#include <vector>
 
 using namespace scm;
 
@@ -39,9 +40,54 @@ static bool view_ok(const scm_view4& v) {
 static TensorBHND cview(const scm_view4& v) { return {(const bf16*)v.p, (long)v.sb, (long)v.sh, (long)v.sn}; }
 static TensorBHND_out oview(const scm_view4& v) { return {(bf16*)v.p, (long)v.sb, (long)v.sh, (long)v.sn}; }
 
+// ---------------------------------------------------------------------------- per-kernel event tracing
+namespace scm {
+static const char* const kKernelNames[K_COUNT] = {
+    "gemm_nt", "wgrad", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
+    "head_bwd", "colsum_reduce", "prep_omega", "favor_kmax", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix"};
+struct TraceRec { int kid; double flops; hipEvent_t t0, t1; };
+static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
+static std::vector<TraceRec> g_trace;
+static bool trace_on(int kid) { return g_trace_kid == K_COUNT || g_trace_kid == kid; }
+void trace_begin(int kid, double flops, hipStream_t s) {
+  if (!trace_on(kid)) return;
+  TraceRec r{kid, flops, nullptr, nullptr};
+  if (hipEventCreate(&r.t0) != hipSuccess || hipEventCreate(&r.t1) != hipSuccess) return;
+  (void)hipEventRecord(r.t0, s);
+  g_trace.push_back(r);
+}
+void trace_end(int kid, hipStream_t s) {
+  if (!trace_on(kid) || g_trace.empty()) return;
+  (void)hipEventRecord(g_trace.back().t1, s);
+}
+}  // namespace scm
+
 extern "C" {
 
 int scm_version(void) { return 1; }
+
+int scm_trace_kernel_count(void) { return K_COUNT; }
+const char* scm_trace_kernel_name(int kid) { return (kid >= 0 && kid < K_COUNT) ? kKernelNames[kid] : ""; }
+int scm_trace_enable(int kid) {
+  SCM_REQ(kid >= -1 && kid <= K_COUNT, "scm_trace_enable: kernel id out of range");
+  g_trace_kid = kid;
+  return 0;
+}
+int scm_trace_collect(double* ms, double* flops, int64_t* launches) {
+  SCM_REQ(ms && flops && launches, "scm_trace_collect: null pointer");
+  for (int i = 0; i < K_COUNT; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (auto& r : g_trace) {
+    float dt = 0.f;
+    if (hipEventSynchronize(r.t1) == hipSuccess && hipEventElapsedTime(&dt, r.t0, r.t1) == hipSuccess) {
+      ms[r.kid] += dt; flops[r.kid] += r.flops; launches[r.kid] += 1;
+    }
+    (void)hipEventDestroy(r.t0);
+    (void)hipEventDestroy(r.t1);
+  }
+  g_trace.clear();
+  return 0;
+}
 const char* scm_last_error(void) { return g_err; }
 
 int scm_cast_weight(const float* src, int rows, int cols, void* dst, void* dstT, void* stream) {
@@ -155,7 +201,7 @@ int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan) {
 
 int64_t scm_favor_ws_floats(const scm_favor_plan* p) {
   if (!p) return 0;
-  return (int64_t)p->B * p->H * p->ctx_chunks * CTX_PART;
+  return (int64_t)p->B * p->H * ((int64_t)p->ctx_chunks * CTX_PART + CTX_FIN_SCRATCH);
 }
 
 static int plan_ok(const scm_favor_plan* p) {
@@ -179,7 +225,9 @@ int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   c.stab = kmax; c.nstab = plan->kmax_chunks * B * H; c.den = nullptr; c.dden = nullptr;
   c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(0, c, B, plan->ctx_chunks, s), "favor_ctx");
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 0, nullptr, ctx_bf16, z, sums, s), "favor_ctx_finalize");
+  float* fin = ws + (int64_t)B * H * plan->ctx_chunks * CTX_PART;
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 0, nullptr, ctx_bf16, z, sums, fin, s),
+          "favor_ctx_finalize");
   ApplyArgs a{};
   a.x = cview(q); a.omega_b = (const bf16*)omega_b; a.Mb = (const bf16*)ctx_bf16; a.zf = z; a.sums = sums;
   a.out0 = oview(out); a.out1 = oview(out_centered); a.rowmax_out = rowmax; a.den_out = den; a.H = H; a.N = N;
@@ -209,7 +257,8 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   c.x = cview(q); c.y = cview(dout); c.omega_b = (const bf16*)omega_b; c.stab = rowmax; c.nstab = 0; c.den = den;
   c.dden = dden; c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(1, c, B, plan->ctx_chunks, s), "favor_ctx(dC)");
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 1, sums, dctx_bf16, dz, dsums, s),
+  float* fin = ws + (int64_t)B * H * plan->ctx_chunks * CTX_PART;
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 1, sums, dctx_bf16, dz, dsums, fin, s),
           "favor_ctx_finalize(dC)");
   // 3. key side: dk, dv
   ApplyArgs g{};

@@ -315,28 +315,22 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
   }
 }
 
-// Sum chunk partials, add the analytic eps terms.  With M = sum_c CE + eps * ysum, zz = sum_c zE + eps * wsum:
-//  mode 0 (forward context): z = zz, obar[d] = colsum(M)[d] / sum(z), writes the CENTRED context
-//      Mb[m,d] = bf16(M[m,d] - z[m] * obar[d]), zf = z, sums[0..63] = obar, sums[64] = sum(z).
-//  mode 1 (backward): Mb = bf16(M) = dC, sums[0..63] = colsum(dC), and, the partial z-sums having been
-//      taken against the centred denominator gradient, zf[m] = zz[m] - dC[m,:] . obar_fwd.
-__global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __restrict__ part, int nchunks, int mode,
-                                                                 const float* __restrict__ sums_fwd,
-                                                                 bf16* __restrict__ Mb, float* __restrict__ zf,
-                                                                 float* __restrict__ sums) {
+// Finalize, stage 1 (grid: bh x 9 feature tiles): sum the chunk partials of 32 features, add the analytic
+// eps terms: M[m,d] = sum_c CE + eps * ysum[d], zz[m] = sum_c zE + eps * wsum.  Writes M (f32), zz and the
+// tile's column sums of M / sum of zz.
+__global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __restrict__ part, int nchunks,
+                                                               float* __restrict__ M32, float* __restrict__ zz,
+                                                               float* __restrict__ colpart /*[bh][9][80]*/) {
   __shared__ float ysum[DH];
-  __shared__ float obar[DH];
   __shared__ float wsum;
   __shared__ float colp[4][DH];
-  __shared__ float zl[NFP];
-  __shared__ float zp[256];
-  const int tid = threadIdx.x, bh = blockIdx.x;
+  __shared__ float zl[32];
+  const int tid = threadIdx.x, bh = blockIdx.x, tile = blockIdx.y;
   const float* base = part + (long)bh * nchunks * CTX_PART;
   if (tid < DH) {
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NFP + tid];
     ysum[tid] = s;
-    if (mode == 1) obar[tid] = sums_fwd[(long)bh * SUMS_STRIDE + tid];
   }
   if (tid == 64) {
     float s = 0.f;
@@ -344,53 +338,76 @@ __global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __
     wsum = s;
   }
   __syncthreads();
-  float zs = 0.f;
-  for (int m = tid; m < NFP; m += 256) {
+  if (tid < 32) {
+    const int m = 32 * tile + tid;
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + m];
     const float v = (m < NF) ? s + KEPS * wsum : 0.f;
-    zl[m] = v;
-    zs += v;
+    zl[tid] = v;
+    zz[(long)bh * NFP + m] = v;
   }
-  zp[tid] = zs;
-  // thread -> column d = tid & 63 (one wave per q), rows m = q + 4*i
   const int d = tid & 63, q = tid >> 6;
   float csum = 0.f;
-  for (int m = q; m < NF; m += 4) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = 32 * tile + q + 4 * i;
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + m * DH + d];
-    csum += s + KEPS * ysum[d];
+    const float v = (m < NF) ? s + KEPS * ysum[d] : 0.f;
+    M32[((long)bh * NFP + m) * DH + d] = v;
+    csum += v;
   }
   colp[q][d] = csum;
   __syncthreads();
-  float zsum = 0.f;
-  if (mode == 0) {
-    for (int i = 0; i < 256; ++i) zsum += zp[i];
-    if (tid < DH) obar[tid] = (colp[0][tid] + colp[1][tid] + colp[2][tid] + colp[3][tid]) / zsum;
-    __syncthreads();
+  float* cp = colpart + ((long)bh * NFT + tile) * SUMS_STRIDE;
+  if (tid < DH) cp[tid] = colp[0][tid] + colp[1][tid] + colp[2][tid] + colp[3][tid];
+  if (tid == 64) {
+    float s = 0.f;
+    for (int i = 0; i < 32; ++i) s += zl[i];
+    cp[DH] = s;
   }
-  for (int m = q; m < NFP; m += 4) {
-    float v = 0.f;
-    if (m < NF) {
-      float s = 0.f;
-      for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + m * DH + d];
-      v = s + KEPS * ysum[d];
-    }
+}
+
+// Finalize, stage 2 (grid: bh x 9):
+//  mode 0 (forward context): z = zz, obar[d] = colsum(M)[d] / sum(z), writes the CENTRED context
+//      Mb[m,d] = bf16(M[m,d] - z[m] * obar[d]), zf = z, sums[0..63] = obar, sums[64] = sum(z).
+//  mode 1 (backward): Mb = bf16(M) = dC, sums[0..63] = colsum(dC), and, the partial z-sums having been
+//      taken against the centred denominator gradient, zf[m] = zz[m] - dC[m,:] . obar_fwd.
+__global__ __launch_bounds__(256) void favor_ctx_finalize_kernel(const float* __restrict__ M32,
+                                                                 const float* __restrict__ zz,
+                                                                 const float* __restrict__ colpart, int mode,
+                                                                 const float* __restrict__ sums_fwd,
+                                                                 bf16* __restrict__ Mb, float* __restrict__ zf,
+                                                                 float* __restrict__ sums) {
+  __shared__ float obar[DH];
+  __shared__ float cs[DH + 1];
+  const int tid = threadIdx.x, bh = blockIdx.x, tile = blockIdx.y;
+  if (tid <= DH) {
+    float s = 0.f;
+    for (int t = 0; t < NFT; ++t) s += colpart[((long)bh * NFT + t) * SUMS_STRIDE + tid];
+    cs[tid] = s;
+  }
+  __syncthreads();
+  if (tid < DH) obar[tid] = (mode == 0) ? cs[tid] / cs[DH] : sums_fwd[(long)bh * SUMS_STRIDE + tid];
+  __syncthreads();
+  const int d = tid & 63, q = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = 32 * tile + q + 4 * i;
+    const float v = M32[((long)bh * NFP + m) * DH + d];
+    const float z = zz[(long)bh * NFP + m];
     if (mode == 0) {
-      Mb[((long)bh * NFP + m) * DH + d] = (bf16)((m < NF) ? v - zl[m] * obar[d] : 0.f);
+      Mb[((long)bh * NFP + m) * DH + d] = (bf16)((m < NF) ? v - z * obar[d] : 0.f);
+      if (d == 0) zf[(long)bh * NFP + m] = z;
     } else {
       Mb[((long)bh * NFP + m) * DH + d] = (bf16)v;
       const float dot = wave_sum(v * obar[d]);  // the 64 lanes of this wave hold row m
-      if (d == 0) zf[(long)bh * NFP + m] = (m < NF) ? zl[m] - dot : 0.f;
+      if (d == 0) zf[(long)bh * NFP + m] = (m < NF) ? z - dot : 0.f;
     }
   }
-  if (mode == 0) {
-    for (int m = tid; m < NFP; m += 256) zf[(long)bh * NFP + m] = zl[m];
-    if (tid < DH) sums[(long)bh * SUMS_STRIDE + tid] = obar[tid];
-    if (tid == 0) sums[(long)bh * SUMS_STRIDE + DH] = zsum;
-  } else {
-    if (tid < DH) sums[(long)bh * SUMS_STRIDE + tid] = colp[0][tid] + colp[1][tid] + colp[2][tid] + colp[3][tid];
-    if (tid == 0) sums[(long)bh * SUMS_STRIDE + DH] = 0.f;
+  if (tile == 0) {
+    if (tid < DH) sums[(long)bh * SUMS_STRIDE + tid] = (mode == 0) ? obar[tid] : cs[tid];
+    if (tid == 0) sums[(long)bh * SUMS_STRIDE + DH] = (mode == 0) ? cs[DH] : 0.f;
   }
 }
 
@@ -694,6 +711,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
 // host launchers
 // ------------------------------------------------------------------------------------------
 hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s) {
+  Traced tr(K_PREP_OMEGA, 0, s);
   hipLaunchKernelGGL(favor_prep_omega_kernel, dim3((NFP * DH + 255) / 256), dim3(256), 0, s, omega, (bf16*)out);
   return hipGetLastError();
 }
@@ -703,6 +721,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, int nchunks, float* part,
                       long long* part_key, hipStream_t s) {
   const int chunk_len = round_up((N + nchunks - 1) / nchunks, 32);
+  Traced tr(K_KMAX, 0, s);
   hipLaunchKernelGGL(favor_kmax_kernel, dim3(nchunks, B * H), dim3(256), 0, s, k, (const bf16*)omega_b, H, N,
                      chunk_len, part, part_key);
   return hipGetLastError();
@@ -710,6 +729,7 @@ hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, in
 
 hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
                       const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s) {
+  Traced tr(K_KFIX, 0, s);
   hipLaunchKernelGGL(favor_kfix_kernel, dim3(1), dim3(64), 0, s, part_val, part_key, nstab, ksum_part, nsum,
                      (const bf16*)omega_b, dk, H, N);
   return hipGetLastError();
@@ -718,6 +738,10 @@ hipError_t favor_kfix(const float* part_val, const long long* part_key, int nsta
 hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
   a.chunk_len = round_up((a.N + nchunks - 1) / nchunks, CTX_TILE);
   const size_t lds = 2 * CTX_BUF + 80 * sizeof(float);
+  // algorithmic GEMM-term FLOPs per (token, head): mode 0: scores 2*64*266 + K'^T V 2*266*64;
+  // mode 1: q'^T dnum 2*266*64 + dz 2*266 (the recomputed scores are not counted)
+  const double th = (double)B * a.H * a.N;
+  Traced tr(mode == 0 ? K_CTX_FWD : K_CTX_BWD, th * (mode == 0 ? 68096.0 : 34580.0), s);
   if (mode == 0)
     hipLaunchKernelGGL((favor_ctx_kernel<0>), dim3(nchunks, B * a.H), dim3(576), lds, s, a);
   else
@@ -725,10 +749,16 @@ hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
   return hipGetLastError();
 }
 
+// scratch: BH * (288*64 + 288 + 9*80) floats placed by the caller after the chunk partials
 hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* sums_fwd, void* Mb,
-                              float* zf, float* sums, hipStream_t s) {
-  hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH), dim3(256), 0, s, part, nchunks, mode, sums_fwd, (bf16*)Mb,
-                     zf, sums);
+                              float* zf, float* sums, float* scratch, hipStream_t s) {
+  float* M32 = scratch;
+  float* zz = M32 + (long)BH * NFP * DH;
+  float* colpart = zz + (long)BH * NFP;
+  Traced tr(K_CTX_FINALIZE, 0, s);
+  hipLaunchKernelGGL(favor_ctx_reduce_kernel, dim3(BH, NFT), dim3(256), 0, s, part, nchunks, M32, zz, colpart);
+  hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH, NFT), dim3(256), 0, s, M32, zz, colpart, mode, sums_fwd,
+                     (bf16*)Mb, zf, sums);
   return hipGetLastError();
 }
 
@@ -745,6 +775,11 @@ hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s)
     attr_set = true;
   }
   dim3 grid(nchunks, B * a.H);
+  // algorithmic FLOPs per (token, head): mode 0: scores + q'C + q'.z = 68,628; mode 1: dnum C^T + dden z +
+  // dS Omega = 68,628; mode 2: v dC^T + k' dC + dS Omega = 102,144 (recomputed scores not counted)
+  const double th = (double)B * a.H * a.N;
+  Traced tr(mode == 0 ? K_APPLY_FWD : (mode == 1 ? K_APPLY_BWD_Q : K_APPLY_BWD_K),
+            th * (mode == 2 ? 102144.0 : 68628.0), s);
   if (mode == 0) hipLaunchKernelGGL((favor_apply_kernel<0>), grid, dim3(512), lds, s, a);
   else if (mode == 1) hipLaunchKernelGGL((favor_apply_kernel<1>), grid, dim3(512), lds, s, a);
   else hipLaunchKernelGGL((favor_apply_kernel<2>), grid, dim3(512), lds, s, a);

@@ -325,6 +325,7 @@ static hipError_t launch_gemm(const void* A, long lda, const bf16* W, long ldw, 
   constexpr int BN = NT * 32;
   dim3 grid((M + G_BM - 1) / G_BM, (N + BN - 1) / BN);
   size_t lds = (size_t)(G_BM + BN) * 128;
+  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s);
   hipLaunchKernelGGL((gemm_nt_kernel<NT, A_F32, EPI>), grid, dim3(256), lds, s, A, lda, W, ldw, M, N, K, e);
   return hipGetLastError();
 }
@@ -364,6 +365,7 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
   dim3 grid((P + W_BP - 1) / W_BP, slices);
   size_t lds = (size_t)W_BT * (W_PP + W_QP);
   const bf16* Pb = (const bf16*)Pm;
+  Traced tr(K_WGRAD, 2.0 * T * P * Q, s);
   if (q_f32 && ones)
     hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(320), lds, s, Pb, ldp, Qm, ldq, T, P, Q, tps, slab);
   else if (q_f32)
@@ -378,6 +380,7 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
 hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, float* bias, int trans, int accumulate,
                         hipStream_t s) {
   const int n = P * (bias ? Q + 1 : Q);
+  Traced tr(K_WGRAD_REDUCE, 0, s);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slab, S, P, Q, grad, bias, trans,
                      accumulate);
   return hipGetLastError();
@@ -385,6 +388,7 @@ hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, flo
 
 hipError_t cast_weight(const float* src, int R, int C, void* dst, void* dstT, hipStream_t s) {
   const int n = R * C;
+  Traced tr(K_CAST, 0, s);
   hipLaunchKernelGGL(cast_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, R, C, (bf16*)dst, (bf16*)dstT);
   return hipGetLastError();
 }

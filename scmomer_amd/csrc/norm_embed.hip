@@ -310,14 +310,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
-// out[i] (+)= sum_b partial[b][i]
-__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int nblocks, int width, int lo, int hi,
-                                     float* __restrict__ out, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= hi - lo) return;
+// out[i] (+)= sum_b partial[b][lo + i].  Workgroup = 32 columns x 8 row groups; fixed summation order.
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, int nblocks, int width,
+                                                            int lo, int hi, float* __restrict__ out, int accumulate) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * width + lo + i];
-  out[i] = accumulate ? out[i] + s : s;
+  if (i < hi - lo) {
+    const float* p = partial + lo + i;
+    int b = rg;
+    for (; b + 24 < nblocks; b += 32) {
+      const float a0 = p[(long)b * width], a1 = p[(long)(b + 8) * width];
+      const float a2 = p[(long)(b + 16) * width], a3 = p[(long)(b + 24) * width];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < nblocks; b += 8) s += p[(long)b * width];
+  }
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && i < hi - lo) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    out[i] = accumulate ? out[i] + t : t;
+  }
 }
 
 // ---------------------------------------------------------------- host launchers
@@ -328,28 +345,33 @@ static int row_grid(long T) {
 
 hipError_t embed_fwd(const int64_t* tok, const float* E, const double* G, int B, int N, int D, int V, float* out,
                      int* err, hipStream_t s) {
+  Traced tr(K_EMBED_FWD, 0, s);
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(row_grid(N)), dim3(256), 0, s, tok, E, G, B, N, D, V, out, err);
   return hipGetLastError();
 }
 int embed_bwd_blocks(long T) { long b = (T + 255) / 256; return (int)(b < 512 ? (b < 1 ? 1 : b) : 512); }
 hipError_t embed_bwd(const int64_t* tok, const float* dx, long T, int D, int V, float* partial, hipStream_t s) {
+  Traced tr(K_EMBED_BWD, 0, s);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(embed_bwd_blocks(T)), dim3(256), 0, s, tok, dx, T, D, V, partial);
   return hipGetLastError();
 }
 hipError_t ln_fwd(const float* x, const float* g, const float* b, long T, int D, void* y, float* mean, float* rstd,
                   hipStream_t s) {
+  Traced tr(K_LN_FWD, 0, s);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(row_grid(T)), dim3(256), 0, s, x, g, b, T, D, (bf16*)y, mean, rstd);
   return hipGetLastError();
 }
 int ln_bwd_blocks(long T) { long b = (T + 63) / 64; return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024); }
 hipError_t ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                   const float* dres, long T, int D, float* dx, float* partial, hipStream_t s) {
+  Traced tr(K_LN_BWD, 0, s);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_blocks(T)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, T, D, dx,
                      partial);
   return hipGetLastError();
 }
 hipError_t head_fwd(const float* x, const float* g, const float* b, const float* W, const float* bias, long T, int D,
                     int C, int relu, float* enc, float* out, float* mean, float* rstd, hipStream_t s) {
+  Traced tr(K_HEAD_FWD, 0, s);
   hipLaunchKernelGGL(head_fwd_kernel, dim3(row_grid(T)), dim3(256), 0, s, x, g, b, W, bias, T, D, C, relu, enc, out,
                      mean, rstd);
   return hipGetLastError();
@@ -358,6 +380,7 @@ hipError_t head_bwd(const float* dout, const float* denc, const float* out, cons
                     const float* rstd, const float* gamma, const float* beta, const float* W, long T, int D, int C,
                     int relu, float* dx, float* partial, hipStream_t s) {
   size_t lds = (size_t)4 * ((2 + C) * 256 + 64) * sizeof(float);
+  Traced tr(K_HEAD_BWD, 0, s);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(ln_bwd_blocks(T)), dim3(256), lds, s, dout, denc, out, x, mean, rstd, gamma,
                      beta, W, T, D, C, relu, dx, partial);
   return hipGetLastError();
@@ -365,7 +388,8 @@ hipError_t head_bwd(const float* dout, const float* denc, const float* out, cons
 hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, int hi, float* out, int accumulate,
                          hipStream_t s) {
   const int n = hi - lo;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nblocks, width, lo, hi, out,
+  Traced tr(K_COLSUM, 0, s);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, nblocks, width, lo, hi, out,
                      accumulate);
   return hipGetLastError();
 }

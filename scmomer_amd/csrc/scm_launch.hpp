@@ -54,6 +54,20 @@ struct ApplyArgs {
 
 constexpr int W_LDSLAB = 208;   // floats per wgrad slab row
 
+// Optional per-kernel timing with HIP events on the launch stream (scm_trace_* in the C ABI).
+enum KernelId {
+  K_GEMM_NT = 0, K_WGRAD, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
+  K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_KMAX, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
+  K_APPLY_BWD_K, K_KFIX, K_COUNT
+};
+void trace_begin(int kid, double flops, hipStream_t s);
+void trace_end(int kid, hipStream_t s);
+struct Traced {  // brackets one launch
+  int kid; hipStream_t s;
+  Traced(int k, double flops, hipStream_t st) : kid(k), s(st) { trace_begin(k, flops, st); }
+  ~Traced() { trace_end(kid, s); }
+};
+
 // gemm.hip
 hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                    GemmEpi e, hipStream_t s);
@@ -88,8 +102,9 @@ hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, in
 hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
                       const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s);
 hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s);
+constexpr int CTX_FIN_SCRATCH = NFP * DH + NFP + NFT * SUMS_STRIDE;  // floats per (b,h) of finalize scratch
 hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* sums_fwd, void* Mb,
-                              float* zf, float* sums, hipStream_t s);
+                              float* zf, float* sums, float* scratch, hipStream_t s);
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s);
 
 }  // namespace scm

@@ -225,3 +225,24 @@ def head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, w, relu: bool, dgamma,
                            _p(w) if c else None, t, d, c, int(relu), _p(dx), _p(ws), _p(dgamma), _p(dbeta),
                            _p(dw) if c else None, _p(db) if c else None, int(accumulate), _stream()), "scm_head_bwd")
     return dx
+
+
+# ----------------------------------------------------------------------------- per-kernel timing
+def trace_kernel_names():
+    return [lib.scm_trace_kernel_name(i).decode() for i in range(lib.scm_trace_kernel_count())]
+
+
+def trace_enable(which):
+    """which: None (off), 'all', or a kernel name from trace_kernel_names()."""
+    names = trace_kernel_names()
+    kid = -1 if which is None else (len(names) if which == "all" else names.index(which))
+    check(lib.scm_trace_enable(kid), "scm_trace_enable")
+
+
+def trace_collect():
+    """-> {name: (milliseconds, algorithmic_flops, launches)} for kernels with launches; clears the log."""
+    n = lib.scm_trace_kernel_count()
+    ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+    check(lib.scm_trace_collect(ms, fl, cnt), "scm_trace_collect")
+    names = trace_kernel_names()
+    return {names[i]: (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}

@@ -53,13 +53,20 @@ class WeightCache:
     """bf16 (and transposed bf16) copies of the f32 master weights, refreshed when a parameter's
     storage or version counter changes (optimizer steps and load_state_dict bump the version)."""
 
+    enabled = True   # set False when forward is captured into a graph: the casts must replay with it
+
     def __init__(self):
         self.store: Dict[Any, Tuple[tuple, dict]] = {}
 
     def attn(self, key, p) -> dict:
         ver = _ver(p["wq"], p["wk"], p["wv"], p["wo"], p["omega"], p["bq"], p["bk"], p["bv"])
         hit = self.store.get(("a", key))
-        if hit is not None and hit[0] == ver:
+        if torch.cuda.is_current_stream_capturing():
+            # casts made while capturing belong to that graph and are replayed with it
+            if hit is not None and hit[0] == ("captured",):
+                return hit[1]
+            ver = ("captured",)
+        elif hit is not None and hit[0] == ver and WeightCache.enabled:
             return hit[1]
         with torch.no_grad():
             wqkv = torch.cat([p["wq"], p["wk"], p["wv"]], 0).to(F32).contiguous()
@@ -76,7 +83,12 @@ class WeightCache:
     def ffn(self, key, p) -> dict:
         ver = _ver(p["w1"], p["w2"])
         hit = self.store.get(("f", key))
-        if hit is not None and hit[0] == ver:
+        if torch.cuda.is_current_stream_capturing():
+            # casts made while capturing belong to that graph and are replayed with it
+            if hit is not None and hit[0] == ("captured",):
+                return hit[1]
+            ver = ("captured",)
+        elif hit is not None and hit[0] == ver and WeightCache.enabled:
             return hit[1]
         with torch.no_grad():
             w1_b, w1_t = ops.cast_weight(p["w1"].detach().to(F32).contiguous())
