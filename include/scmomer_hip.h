@@ -64,7 +64,8 @@ int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* 
                float* dres_colsum, int accumulate, void* stream);
 
 /* ---- nn.Linear products: performer_pytorch.py:374 (to_q/k/v), :402 (to_out), :323,330 (FeedForward) ---- */
-/* Y[M,N] = A[M,K] * W[N,K]^T with a fused epilogue; A is bf16 or (a_f32) f32, W bf16, K % 8 == 0.
+/* Y[M,N] = A[M,K] * W[N,K]^T with a fused epilogue; A is bf16 or (a_f32) f32, W bf16, K % 8 == 0, N % 8 == 0,
+ * leading dimensions multiples of 8 elements and 16-byte aligned bases.
  *   SCM_EPI_BF16          out0 bf16 = acc
  *   SCM_EPI_F32_BIAS_RES  out0 f32  = acc + bias[n] + resid[m,n]     (bias/resid may be NULL; reversible.py:144-145)
  *   SCM_EPI_GELU_DUAL     out0 bf16 = acc + bias ; out1 bf16 = gelu_erf(acc + bias)   (nn.GELU, :313)

@@ -155,11 +155,16 @@ int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W, i
                 void* out0, int64_t ldo0, void* out1, int64_t ldo1, const float* bias, const float* resid, int64_t ldr,
                 const void* pre, int64_t ldp, void* stream) {
   SCM_REQ(A && W && out0, "scm_gemm_nt: null pointer");
-  SCM_REQ(M > 0 && N > 0 && K > 0 && K % 8 == 0, "scm_gemm_nt: need K%%8==0 (M=%d N=%d K=%d)", M, N, K);
+  SCM_REQ(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0, "scm_gemm_nt: need K%%8==0, N%%8==0 (M=%d N=%d K=%d)",
+          M, N, K);
   SCM_REQ(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "scm_gemm_nt: lda/ldw must be >=K and %%8==0");
   SCM_REQ(aligned16(A) && aligned16(W), "scm_gemm_nt: A/W must be 16-byte aligned");
   SCM_REQ(epi >= 0 && epi <= 5, "scm_gemm_nt: unknown epilogue %d", epi);
-  SCM_REQ(ldo0 >= N, "scm_gemm_nt: ldo0 < N");
+  SCM_REQ(ldo0 >= N && ldo0 % 8 == 0 && aligned16(out0), "scm_gemm_nt: out0 needs ldo0 >= N, ldo0%%8==0, 16-byte base");
+  SCM_REQ(!out1 || (ldo1 % 8 == 0 && aligned16(out1)), "scm_gemm_nt: out1 needs ldo1%%8==0, 16-byte base");
+  SCM_REQ(!resid || (ldr % 4 == 0 && aligned16(resid)), "scm_gemm_nt: resid needs ldr%%4==0, 16-byte base");
+  SCM_REQ(!pre || (ldp % 8 == 0 && aligned16(pre)), "scm_gemm_nt: pre needs ldp%%8==0, 16-byte base");
+  SCM_REQ(!bias || aligned16(bias), "scm_gemm_nt: bias must be 16-byte aligned");
   if (epi == SCM_EPI_GELU_DUAL) SCM_REQ(out1 && ldo1 >= N, "scm_gemm_nt: GELU_DUAL needs out1");
   if (epi == SCM_EPI_DGELU) SCM_REQ(pre && ldp >= N, "scm_gemm_nt: DGELU needs pre");
   if (resid) SCM_REQ(ldr >= N, "scm_gemm_nt: ldr < N");

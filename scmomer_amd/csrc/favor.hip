@@ -347,13 +347,19 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
     zz[(long)bh * NFP + m] = v;
   }
   const int d = tid & 63, q = tid >> 6;
+  float acc8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
+  for (int c = 0; c < nchunks; ++c) {   // 8 independent loads in flight per chunk
+    const float* rec = base + (long)c * CTX_PART + (32 * tile + q) * DH + d;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc8[i] += rec[4 * i * DH];
+  }
   float csum = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = 32 * tile + q + 4 * i;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + m * DH + d];
-    const float v = (m < NF) ? s + KEPS * ysum[d] : 0.f;
+    const float v = (m < NF) ? acc8[i] + KEPS * ysum[d] : 0.f;
     M32[((long)bh * NFP + m) * DH + d] = v;
     csum += v;
   }

@@ -19,6 +19,7 @@ enum { EPI_BF16 = 0, EPI_F32_BIAS_RES = 1, EPI_GELU_DUAL = 2, EPI_DGELU = 3, EPI
 
 constexpr int G_BM = 128;
 constexpr int G_BK = 64;
+constexpr int G_SP = 68;   // floats per staged epilogue row (64 + 4: rows 16-byte aligned, conflict-free)
 
 template <int NT, bool A_F32>
 struct GemmStage {
@@ -110,36 +111,71 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const void* __restrict__ A
     __syncthreads();
   }
 
-  // epilogue: element r of acc[t] is row m0+32w+acc_row(r,half), column n0+32t+(l&31)
+  // Epilogue through LDS: accumulator tiles (column on the lane, rows in registers) are staged per wave as
+  // [32 rows][64 columns] f32, then read back row-wise so that every lane handles 8 consecutive columns of
+  // one row: 16-byte (bf16) / 32-byte (f32) global stores, 128..256 contiguous bytes per row, and the
+  // bias / residual / pre-activation operands are read with the same coalesced shape.
+  float* stage = (float*)smem + w * (32 * G_SP);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = n0 + 32 * t + (l & 31);
-    if (col >= N) continue;
-    float bias = 0.f;
-    if (EPI == EPI_F32_BIAS_RES || EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) bias = e.bias ? e.bias[col] : 0.f;
+  for (int tp = 0; tp < (NT + 1) / 2; ++tp) {
+    const int t0 = 2 * tp, t1 = 2 * tp + 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + 32 * w + acc_row(r, half);
-      if (row >= M) continue;
-      float v = acc[t][r];
-      if (EPI == EPI_BF16) {
-        ((bf16*)e.out0)[(long)row * e.ldo0 + col] = (bf16)v;
-      } else if (EPI == EPI_BF16_BIAS) {
-        ((bf16*)e.out0)[(long)row * e.ldo0 + col] = (bf16)(v + bias);
-      } else if (EPI == EPI_F32) {
-        ((float*)e.out0)[(long)row * e.ldo0 + col] = v;
-      } else if (EPI == EPI_F32_BIAS_RES) {
-        float rres = e.resid ? e.resid[(long)row * e.ldr + col] : 0.f;
-        ((float*)e.out0)[(long)row * e.ldo0 + col] = v + bias + rres;
+      stage[acc_row(r, half) * G_SP + (l & 31)] = acc[t0][r];
+      if (t1 < NT) stage[acc_row(r, half) * G_SP + 32 + (l & 31)] = acc[t1][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int ch = l & 7;
+    const int col = n0 + 64 * tp + 8 * ch;
+    const bool col_ok = (t1 < NT || ch < 4) && col < N;
+    float bias[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias[j] = 0.f;
+    if ((EPI == EPI_F32_BIAS_RES || EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) && e.bias && col_ok) {
+      const f32x4 b0 = *(const f32x4*)(e.bias + col), b1 = *(const f32x4*)(e.bias + col + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bias[j] = b0[j]; bias[4 + j] = b1[j]; }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int rl = 8 * pass + (l >> 3);
+      const long row = m0 + 32 * w + rl;
+      if (!col_ok || row >= M) continue;
+      const f32x4 a0 = *(const f32x4*)(stage + rl * G_SP + 8 * ch);
+      const f32x4 a1 = *(const f32x4*)(stage + rl * G_SP + 8 * ch + 4);
+      float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bias[j];
+      if (EPI == EPI_BF16 || EPI == EPI_BF16_BIAS) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+        *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
+      } else if (EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES) {
+        if (EPI == EPI_F32_BIAS_RES && e.resid) {
+          const f32x4 r0 = *(const f32x4*)(e.resid + row * e.ldr + col);
+          const f32x4 r1 = *(const f32x4*)(e.resid + row * e.ldr + col + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
+        }
+        float* op = (float*)e.out0 + row * e.ldo0 + col;
+        *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
       } else if (EPI == EPI_GELU_DUAL) {
-        float p = v + bias;
-        ((bf16*)e.out0)[(long)row * e.ldo0 + col] = (bf16)p;
-        ((bf16*)e.out1)[(long)row * e.ldo1 + col] = (bf16)gelu_erf(p);
+        bf16x8 o, g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = (bf16)v[j]; g[j] = (bf16)gelu_erf(v[j]); }
+        *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
+        *(bf16x8*)((bf16*)e.out1 + row * e.ldo1 + col) = g;
       } else if (EPI == EPI_DGELU) {
-        float p = (float)e.pre[(long)row * e.ldp + col];
-        ((bf16*)e.out0)[(long)row * e.ldo0 + col] = (bf16)(v * gelu_erf_grad(p));
+        const bf16x8 pv = *(const bf16x8*)(e.pre + row * e.ldp + col);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * gelu_erf_grad((float)pv[j]));
+        *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -175,8 +211,17 @@ __global__ __launch_bounds__(320) void wgrad_kernel(const bf16* __restrict__ Pm,
   char* Ps = smem;                   // [64][160] bf16
   char* Qs = smem + W_BT * W_PP;     // [64][224] bf16
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
-  const int p0 = blockIdx.x * W_BP;
-  const int slice = blockIdx.y;
+  // 1-D grid of ptiles*slices blocks.  Blocks b and b+8 share an XCD (round-robin dispatch): the P tiles
+  // of one token slice are given ids 8 apart so that they run on one XCD and read the slice's Q-operand
+  // tile (common to all of them) through that XCD's L2.  Speed only: any placement is correct.
+  const int ptiles = (P + W_BP - 1) / W_BP;
+  int slice, ptile;
+  {
+    const int b = blockIdx.x, nslices = gridDim.x / ptiles, full = (nslices / 8) * 8 * ptiles;
+    if (b < full) { slice = (b % 8) + 8 * (b / (8 * ptiles)); ptile = (b / 8) % ptiles; }
+    else { slice = (nslices / 8) * 8 + (b - full) / ptiles; ptile = (b - full) % ptiles; }
+  }
+  const int p0 = ptile * W_BP;
   const int ntiles = (T + W_BT - 1) / W_BT;
   const int tile_lo = slice * tiles_per_slice;
   const int tile_hi = min(ntiles, tile_lo + tiles_per_slice);
@@ -291,8 +336,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int S, int P
   const int qn = bias ? Q + 1 : Q;
   if (idx >= P * qn) return;
   const int p = idx / qn, q = idx % qn;
-  float s = 0.f;
-  for (int i = 0; i < S; ++i) s += slab[((long)i * P + p) * W_LDSLAB + q];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* sp = slab + (long)p * W_LDSLAB + q;
+  const long st = (long)P * W_LDSLAB;
+  int i = 0;
+  for (; i + 3 < S; i += 4) {   // four independent loads in flight; fixed summation order
+    s0 += sp[i * st]; s1 += sp[(i + 1) * st]; s2 += sp[(i + 2) * st]; s3 += sp[(i + 3) * st];
+  }
+  for (; i < S; ++i) s0 += sp[i * st];
+  const float s = (s0 + s1) + (s2 + s3);
   if (q == Q) {
     bias[p] = accumulate ? bias[p] + s : s;
   } else {
@@ -325,6 +377,7 @@ static hipError_t launch_gemm(const void* A, long lda, const bf16* W, long ldw, 
   constexpr int BN = NT * 32;
   dim3 grid((M + G_BM - 1) / G_BM, (N + BN - 1) / BN);
   size_t lds = (size_t)(G_BM + BN) * 128;
+  if (lds < 4 * 32 * G_SP * sizeof(float)) lds = 4 * 32 * G_SP * sizeof(float);
   Traced tr(K_GEMM_NT, 2.0 * M * N * K, s);
   hipLaunchKernelGGL((gemm_nt_kernel<NT, A_F32, EPI>), grid, dim3(256), lds, s, A, lda, W, ldw, M, N, K, e);
   return hipGetLastError();
@@ -362,7 +415,7 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
                  int slices, float* slab, hipStream_t s) {
   const int ntiles = (T + W_BT - 1) / W_BT;
   const int tps = (ntiles + slices - 1) / slices;
-  dim3 grid((P + W_BP - 1) / W_BP, slices);
+  dim3 grid(((P + W_BP - 1) / W_BP) * slices);
   size_t lds = (size_t)W_BT * (W_PP + W_QP);
   const bf16* Pb = (const bf16*)Pm;
   Traced tr(K_WGRAD, 2.0 * T * P * Q, s);

@@ -131,9 +131,11 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, *, out0: torch.Tensor, o
 
 
 def wgrad_slices(t: int, p: int) -> int:
-    """token slices so that (P/160) * slices workgroups fill the 256 CUs about twice"""
+    """token slices so that ceil(P/160) * slices workgroups are about one per CU (256); every slice costs a
+    [P,208] f32 slab of extra traffic, so no more than that"""
     tiles = max(1, (t + 63) // 64)
-    return max(1, min(tiles, (512 * 160) // p))
+    ptiles = (p + 159) // 160
+    return max(1, min(tiles, 256 // ptiles))
 
 
 def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, trans: bool, accumulate: bool):
