@@ -57,11 +57,12 @@ int scm_ln_fwd(const float* x, const float* gamma, const float* beta, int64_t T,
                float* rstd, void* stream);
 /* dx = dres + dLN(dy) (dres may be NULL); dgamma/dbeta (+)= ; dres_colsum (+)= column sums of dres
  * (the bias gradient of the Linear that produced the residual branch; may be NULL).
+ * dx_bf16 (may be NULL): the same dx rounded to bf16, the operand the next data-/weight-gradient products read.
  * ws: scm_ln_bwd_ws_floats(T,D) floats. */
 int64_t scm_ln_bwd_ws_floats(int64_t T, int D);
 int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-               const float* dres, int64_t T, int D, float* dx, float* ws, float* dgamma, float* dbeta,
-               float* dres_colsum, int accumulate, void* stream);
+               const float* dres, int64_t T, int D, float* dx, void* dx_bf16, float* ws, float* dgamma,
+               float* dbeta, float* dres_colsum, int accumulate, void* stream);
 
 /* ---- nn.Linear products: performer_pytorch.py:374 (to_q/k/v), :402 (to_out), :323,330 (FeedForward) ---- */
 /* Y[M,N] = A[M,K] * W[N,K]^T with a fused epilogue; A is bf16 or (a_f32) f32, W bf16, K % 8 == 0, N % 8 == 0,
@@ -121,11 +122,12 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
 int scm_head_fwd(const float* x, const float* gamma, const float* beta, const float* W, const float* bias, int64_t T,
                  int D, int C, int relu, float* enc, float* out, float* mean, float* rstd, void* stream);
 int64_t scm_head_bwd_ws_floats(int64_t T, int D, int C);
-/* dout [T,C] and/or denc [T,D] (either may be NULL) -> dx; dgamma, dbeta, dW [C,D], db [C] (+)= . */
+/* dout [T,C] and/or denc [T,D] (either may be NULL) -> dx (and its bf16 rounding dx_bf16, may be NULL);
+ * dgamma, dbeta, dW [C,D], db [C] (+)= . */
 int scm_head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
                  const float* rstd, const float* gamma, const float* beta, const float* W, int64_t T, int D, int C,
-                 int relu, float* dx, float* ws, float* dgamma, float* dbeta, float* dW, float* db, int accumulate,
-                 void* stream);
+                 int relu, float* dx, void* dx_bf16, float* ws, float* dgamma, float* dbeta, float* dW, float* db,
+                 int accumulate, void* stream);
 
 /* ---- measurement aid (no reference counterpart): per-kernel durations from HIP events recorded on the
  *      launch stream around each launch of the selected kernel.  scm_trace_enable(kid): -1 off,

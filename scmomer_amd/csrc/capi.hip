@@ -5,6 +5,7 @@
 
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <vector>
 
 using namespace scm;
@@ -136,14 +137,15 @@ int scm_ln_fwd(const float* x, const float* gamma, const float* beta, int64_t T,
 int64_t scm_ln_bwd_ws_floats(int64_t T, int D) { return (int64_t)ln_bwd_blocks(T) * 3 * D; }
 
 int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-               const float* dres, int64_t T, int D, float* dx, float* ws, float* dgamma, float* dbeta,
-               float* dres_colsum, int accumulate, void* stream) {
+               const float* dres, int64_t T, int D, float* dx, void* dx_bf16, float* ws, float* dgamma,
+               float* dbeta, float* dres_colsum, int accumulate, void* stream) {
   SCM_REQ(dy && x && mean && rstd && gamma && dx && ws, "scm_ln_bwd: null pointer");
   SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0, "scm_ln_bwd: bad sizes");
-  SCM_REQ(aligned16(dy) && aligned16(x) && aligned16(gamma) && aligned16(dx) && (!dres || aligned16(dres)),
+  SCM_REQ(aligned16(dy) && aligned16(x) && aligned16(gamma) && aligned16(dx) && (!dres || aligned16(dres)) &&
+              (!dx_bf16 || aligned16(dx_bf16)),
           "scm_ln_bwd: unaligned pointer");
   hipStream_t s = (hipStream_t)stream;
-  SCM_HIP(ln_bwd(dy, x, mean, rstd, gamma, dres, T, D, dx, ws, s), "scm_ln_bwd");
+  SCM_HIP(ln_bwd(dy, x, mean, rstd, gamma, dres, T, D, dx, dx_bf16, ws, s), "scm_ln_bwd");
   const int nb = ln_bwd_blocks(T);
   if (dgamma) SCM_HIP(colsum_reduce(ws, nb, 3 * D, 0, D, dgamma, accumulate, s), "scm_ln_bwd(dgamma)");
   if (dbeta) SCM_HIP(colsum_reduce(ws, nb, 3 * D, D, 2 * D, dbeta, accumulate, s), "scm_ln_bwd(dbeta)");
@@ -296,14 +298,14 @@ int64_t scm_head_bwd_ws_floats(int64_t T, int D, int C) { return (int64_t)ln_bwd
 
 int scm_head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
                  const float* rstd, const float* gamma, const float* beta, const float* W, int64_t T, int D, int C,
-                 int relu, float* dx, float* ws, float* dgamma, float* dbeta, float* dW, float* db, int accumulate,
-                 void* stream) {
+                 int relu, float* dx, void* dx_bf16, float* ws, float* dgamma, float* dbeta, float* dW, float* db,
+                 int accumulate, void* stream) {
   SCM_REQ(x && mean && rstd && gamma && beta && dx && ws && (dout || denc), "scm_head_bwd: null pointer");
   SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0 && C >= 0 && C <= 8, "scm_head_bwd: need D<=256, C<=8");
   SCM_REQ(!dout || (W && C > 0 && (!relu || out)), "scm_head_bwd: dout needs W (and out when relu)");
   if (!dout) C = 0;
   hipStream_t s = (hipStream_t)stream;
-  SCM_HIP(head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, W, T, D, C, relu, dx, ws, s), "scm_head_bwd");
+  SCM_HIP(head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, W, T, D, C, relu, dx, dx_bf16, ws, s), "scm_head_bwd");
   const int nb = ln_bwd_blocks(T), wd = head_width(D, C);
   if (dgamma) SCM_HIP(colsum_reduce(ws, nb, wd, 0, D, dgamma, accumulate, s), "scm_head_bwd(dgamma)");
   if (dbeta) SCM_HIP(colsum_reduce(ws, nb, wd, D, 2 * D, dbeta, accumulate, s), "scm_head_bwd(dbeta)");

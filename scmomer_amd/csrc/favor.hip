@@ -26,6 +26,7 @@
 //                       rows with no lane movement.  MODE 0: o, rowmax, den.  MODE 1: dq, dden.
 //                       MODE 2: dk, dv.
 #include "scm_launch.hpp"
+#include <type_traits>
 
 namespace scm {
 
@@ -65,6 +66,37 @@ SCM_DEV float frag_sumsq(const bf16x8 (&f)[4]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float v = (float)f[ks][j]; s += v * v; }
   return xhalf_sum(s);
+}
+
+// Byte offsets of this lane's fragment reads inside one 32-row block (4096 bytes) of a swizzled image.
+// The swizzle depends on row & 15 only, so block t of an image is at +4096*t with the same offsets:
+// they are computed once per kernel instead of once per read.
+struct LaneOffs {
+  int row[4];        // row fragment (k along image columns) of k-step ks: rows l&31, columns 16ks + 8*half
+  int tr[2][2][2];   // transposed fragment in accumulator k order: [k-step sk][32-column block dt][read]
+};
+SCM_DEV LaneOffs lane_offs() {
+  LaneOffs o;
+  const int l = lane_id(), half = l >> 5, g = l >> 4, i = l & 15, q = i >> 2;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) o.row[ks] = img_off(l & 31, 16 * ks + 8 * half);
+#pragma unroll
+  for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int col = 32 * dt + 16 * (g & 1) + 4 * (i & 3);
+      o.tr[sk][dt][0] = img_off(16 * sk + 4 * half + q, col);
+      o.tr[sk][dt][1] = img_off(16 * sk + 8 + 4 * half + q, col);
+    }
+  return o;
+}
+SCM_DEV bf16x8 tr_frag_at(const char* blk, const int (&o)[2]) {
+  const bf16x4 lo4 = lds_tr_read(blk + o[0]);
+  const bf16x4 hi4 = lds_tr_read(blk + o[1]);
+  bf16x8 f;
+  f[0] = lo4[0]; f[1] = lo4[1]; f[2] = lo4[2]; f[3] = lo4[3];
+  f[4] = hi4[0]; f[5] = hi4[1]; f[6] = hi4[2]; f[7] = hi4[3];
+  return f;
 }
 
 // X[m,token] tile t = Omega_t (32x64) * x^T (64x32)
@@ -195,6 +227,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     for (int ks = 0; ks < 4; ++ks) omf[ks] = *(const bf16x8*)(orow + 16 * ks + 8 * half);
   }
   const bool lane_feat_valid = (32 * w + (l & 31)) < NF;
+  const LaneOffs lo = lane_offs();
 
   f32x16 cacc[2] = {zero16(), zero16()};
   float zacc = 0.f;
@@ -264,7 +297,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
       // S[token, feature] = x_tile (32x64) * Omega_w^T (64x32)
       f32x16 s = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s = mfma32(img_row_frag(xs, 32 * sub, 16 * ks), omf[ks], s);
+      for (int ks = 0; ks < 4; ++ks) s = mfma32(*(const bf16x8*)(xs + 4096 * sub + lo.row[ks]), omf[ks], s);
       f32x16 e;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -284,7 +317,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
         const bf16x8 ef = acc_to_frag(e, sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          cacc[dt] = mfma32(ef, img_tr_frag<true>(ys, 32 * sub + 16 * sk, 32 * dt), cacc[dt]);
+          cacc[dt] = mfma32(ef, tr_frag_at(ys + 4096 * sub, lo.tr[sk][dt]), cacc[dt]);
       }
     }
     if (it + 1 < ntiles) write_tile(nbuf);
@@ -506,6 +539,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
   const bf16* xb = a.x.p + b * a.x.sb + h * a.x.sh;
   const long srow = (long)bh * a.N;
   float ksum = 0.f;  // MODE 2: sum over this wave's tokens of sum_m dA
+  const LaneOffs lo = lane_offs();
 
   for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 256) {
     const int n = n0 + (l & 31);
@@ -587,15 +621,19 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
         for (int j = 0; j < 8; ++j) dof[ks][j] = (bf16)((float)dof[ks][j] * inv);
       const float off = (HALF_C2 * norm2 + CNORM * rmx) * LOG2E;
       f32x16 Y[2] = {zero16(), zero16()};
-      float rs = 0.f, rsmax = 0.f;
+      float rs = 0.f, rsm = 0.f;
       int jstar = 1 << 20;
-#pragma unroll 1
-      for (int t = 0; t < NFT; ++t) {
-        const f32x16 X = score_tile(omg, t, xf);
-        // G[m,token] = C'_t (32x64) * dnum^T (64x32) + z[m] * dden   (centred context, centred dden)
-        f32x16 G = zero16();
+      auto tile = [&](int t, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const char* ob_ = omg + t * 4096;
+        const char* mb_ = mim + t * 4096;
+        f32x16 X = zero16(), G = zero16();
+        // X[m,token] = Omega_t q^T ; G[m,token] = C'_t dnum^T (centred context)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) G = mfma32(img_row_frag(mim, 32 * t, 16 * ks), dof[ks], G);
+        for (int ks = 0; ks < 4; ++ks) {
+          X = mfma32(*(const bf16x8*)(ob_ + lo.row[ks]), xf[ks], X);
+          G = mfma32(*(const bf16x8*)(mb_ + lo.row[ks]), dof[ks], G);
+        }
         f32x16 dA;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -604,29 +642,32 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * g + i;
             float e = exp2_fast(X[r] * (CNORM * LOG2E) - off);
-            const bool fv = feat_valid(t, r, half);
-            e = fv ? e : 0.f;
+            const bool fv = !LAST || acc_row(r, half) < NF - 32 * (NFT - 1);
+            if (LAST) e = fv ? e : 0.f;
             const float v = e * (G[r] + z4[i] * dden);
             rs += v;
             // The stabiliser routes -sum(dA) to the arg-max feature j*, so dA[j*] Omega[j*] cancels
             // against it exactly: keep that (largest) element out of the bf16 product and apply the
-            // net coefficient -(sum(dA) - dA[j*]) in f32 at the write-back.
+            // net coefficient -(sum of the other dA) in f32 at the write-back.
             const bool ismax = fv && X[r] == rmx;
-            if (ismax) { jstar = min(jstar, 32 * t + acc_row(r, half)); rsmax += v; }
-            dA[r] = ismax ? 0.f : v;
+            jstar = ismax ? min(jstar, 32 * t + acc_row(r, half)) : jstar;
+            const float vm = ismax ? 0.f : v;
+            dA[r] = vm;
+            rsm += vm;
           }
         }
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk) {
           const bf16x8 af = acc_to_frag(dA, sk);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            Y[dt] = mfma32(img_tr_frag<true>(omg, 32 * t + 16 * sk, 32 * dt), af, Y[dt]);
+          for (int dt = 0; dt < 2; ++dt) Y[dt] = mfma32(tr_frag_at(ob_, lo.tr[sk][dt]), af, Y[dt]);
         }
-      }
-      const float rs_all = xhalf_sum(rs);
-      const float ddiag = -rs_all;
-      const float stabc = -(rs_all - xhalf_sum(rsmax));
+      };
+#pragma unroll 1
+      for (int t = 0; t < NFT - 1; ++t) tile(t, std::false_type{});
+      tile(NFT - 1, std::true_type{});
+      const float ddiag = -xhalf_sum(rs);
+      const float stabc = -xhalf_sum(rsm);
       jstar = min(jstar, __shfl_xor(jstar, 32));
       stage_rows(stage, Y, CNORM, nullptr, 0.f);
       if (l < 32) {
@@ -650,13 +691,17 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       f32x16 Yk[2] = {zero16(), zero16()};
       f32x16 Yv[2] = {zero16(), zero16()};
       float rs = 0.f;
-#pragma unroll 1
-      for (int t = 0; t < NFT; ++t) {
-        const f32x16 X = score_tile(omg, t, xf);
-        // G[m,token] = dC_t (32x64) * v^T (64x32) + dz[m]
-        f32x16 G = zero16();
+      auto tile = [&](int t, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const char* ob_ = omg + t * 4096;
+        const char* mb_ = mim + t * 4096;
+        f32x16 X = zero16(), G = zero16();
+        // X[m,token] = Omega_t k^T ; G[m,token] = dC_t v^T
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) G = mfma32(img_row_frag(mim, 32 * t, 16 * ks), vf[ks], G);
+        for (int ks = 0; ks < 4; ++ks) {
+          X = mfma32(*(const bf16x8*)(ob_ + lo.row[ks]), xf[ks], X);
+          G = mfma32(*(const bf16x8*)(mb_ + lo.row[ks]), vf[ks], G);
+        }
         f32x16 E, dA;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -665,7 +710,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * g + i;
             float e = exp2_fast(X[r] * (CNORM * LOG2E) - off);
-            e = feat_valid(t, r, half) ? e : 0.f;
+            if (LAST) e = (acc_row(r, half) < NF - 32 * (NFT - 1)) ? e : 0.f;
             E[r] = e;
             const float v = e * (G[r] + z4[i]);
             dA[r] = v;
@@ -678,11 +723,14 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           const bf16x8 ef = acc_to_frag(E, sk);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            Yk[dt] = mfma32(img_tr_frag<true>(omg, 32 * t + 16 * sk, 32 * dt), af, Yk[dt]);
-            Yv[dt] = mfma32(img_tr_frag<true>(mim, 32 * t + 16 * sk, 32 * dt), ef, Yv[dt]);
+            Yk[dt] = mfma32(tr_frag_at(ob_, lo.tr[sk][dt]), af, Yk[dt]);
+            Yv[dt] = mfma32(tr_frag_at(mb_, lo.tr[sk][dt]), ef, Yv[dt]);
           }
         }
-      }
+      };
+#pragma unroll 1
+      for (int t = 0; t < NFT - 1; ++t) tile(t, std::false_type{});
+      tile(NFT - 1, std::true_type{});
       const float ddiag = -xhalf_sum(rs);
       if (valid && l < 32) ksum -= ddiag;
       // dv = E dC + eps * colsum(dC)

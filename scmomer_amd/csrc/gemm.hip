@@ -9,6 +9,7 @@
 //  wgrad_reduce : sums the slabs into the f32 gradient (optionally transposed, optional bias
 //            column), deterministic.
 #include "scm_launch.hpp"
+#include <stdlib.h>
 
 namespace scm {
 
@@ -20,6 +21,74 @@ enum { EPI_BF16 = 0, EPI_F32_BIAS_RES = 1, EPI_GELU_DUAL = 2, EPI_DGELU = 3, EPI
 constexpr int G_BM = 128;
 constexpr int G_BK = 64;
 constexpr int G_SP = 68;   // floats per staged epilogue row (64 + 4: rows 16-byte aligned, conflict-free)
+
+// Epilogue of one pair of 32x32 accumulator tiles (columns col0..col0+63; `two` = second tile present).
+// Accumulators (column on the lane, rows in registers) are staged per wave as [32 rows][64 columns] f32,
+// then read back row-wise so that every lane handles 8 consecutive columns of one row: 16-byte (bf16) /
+// 32-byte (f32) global stores, 128..256 contiguous bytes per row; the bias / residual / pre-activation
+// operands are read with the same coalesced shape.
+template <int EPI>
+SCM_DEV void epilogue_pair(float* stage, const f32x16& acc0, const f32x16& acc1, bool two, long row0, int col0,
+                           int M, int N, const GemmEpi& e) {
+  const int l = lane_id(), half = l >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    stage[acc_row(r, half) * G_SP + (l & 31)] = acc0[r];
+    if (two) stage[acc_row(r, half) * G_SP + 32 + (l & 31)] = acc1[r];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int ch = l & 7;
+  const int col = col0 + 8 * ch;
+  const bool col_ok = (two || ch < 4) && col < N;
+  float bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = 0.f;
+  if ((EPI == EPI_F32_BIAS_RES || EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) && e.bias && col_ok) {
+    const f32x4 b0 = *(const f32x4*)(e.bias + col), b1 = *(const f32x4*)(e.bias + col + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bias[j] = b0[j]; bias[4 + j] = b1[j]; }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int rl = 8 * pass + (l >> 3);
+    const long row = row0 + rl;
+    if (!col_ok || row >= M) continue;
+    const f32x4 a0 = *(const f32x4*)(stage + rl * G_SP + 8 * ch);
+    const f32x4 a1 = *(const f32x4*)(stage + rl * G_SP + 8 * ch + 4);
+    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bias[j];
+    if (EPI == EPI_BF16 || EPI == EPI_BF16_BIAS) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+      *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
+    } else if (EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES) {
+      if (EPI == EPI_F32_BIAS_RES && e.resid) {
+        const f32x4 r0 = *(const f32x4*)(e.resid + row * e.ldr + col);
+        const f32x4 r1 = *(const f32x4*)(e.resid + row * e.ldr + col + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
+      }
+      float* op = (float*)e.out0 + row * e.ldo0 + col;
+      *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+      *(f32x4*)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else if (EPI == EPI_GELU_DUAL) {
+      bf16x8 o, g;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o[j] = (bf16)v[j]; g[j] = (bf16)gelu_erf(v[j]); }
+      *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
+      *(bf16x8*)((bf16*)e.out1 + row * e.ldo1 + col) = g;
+    } else if (EPI == EPI_DGELU) {
+      const bf16x8 pv = *(const bf16x8*)(e.pre + row * e.ldp + col);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * gelu_erf_grad((float)pv[j]));
+      *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 
 template <int NT, bool A_F32>
 struct GemmStage {
@@ -36,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const void* __restrict__ A
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                 // [128][64] bf16 swizzled image
   char* Ws = smem + G_BM * 128;    // [BN][64]
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  const int tid = threadIdx.x, w = tid >> 6;
   const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * BN;
   const int nk = (K + G_BK - 1) / G_BK;
 
@@ -90,92 +159,209 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const void* __restrict__ A
     }
   };
 
+  // fragment byte offsets inside a 32-row block of an image, per k-step (hoisted out of the loops)
+  const int l = tid & 63;
+  int roff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) roff[i] = img_off(l & 31, 16 * i + 8 * (l >> 5));
+  const char* Aw = As + 4096 * w;
+
   load_stage(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk_full = K / G_BK;
+  for (int kt = 0; kt < nk_full; ++kt) {      // full k-tiles: straight-line, no branches between MFMAs
     write_stage();
     __syncthreads();
     if (kt + 1 < nk) load_stage(kt + 1);
-    const int krem = K - kt * G_BK;
-    const int ks = krem >= G_BK ? 4 : (krem + 15) >> 4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s < ks) {
-        bf16x8 a = img_row_frag(As, 32 * w, 16 * s);
+      const bf16x8 a = *(const bf16x8*)(Aw + roff[s]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          bf16x8 b = img_row_frag(Ws, 32 * t, 16 * s);
-          acc[t] = mfma32(a, b, acc[t]);
-        }
-      }
+      for (int t = 0; t < NT; ++t) acc[t] = mfma32(a, *(const bf16x8*)(Ws + 4096 * t + roff[s]), acc[t]);
+    }
+    __syncthreads();
+  }
+  if (nk_full < nk) {                          // K tail: a rolled loop over its k-steps (zero padded to 16)
+    write_stage();
+    __syncthreads();
+    const int ks = (K - nk_full * G_BK + 15) >> 4;
+    const int hoff = 16 * (l >> 5);
+#pragma unroll 1
+    for (int s = 0; s < ks; ++s) {
+      // chunk index 2s + half, swizzled per row
+      const int off = (l & 31) * 128 + (swz128(l & 31, 2 * s + (l >> 5)) << 4);
+      (void)hoff;
+      const bf16x8 a = *(const bf16x8*)(Aw + off);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma32(a, *(const bf16x8*)(Ws + 4096 * t + off), acc[t]);
     }
     __syncthreads();
   }
 
-  // Epilogue through LDS: accumulator tiles (column on the lane, rows in registers) are staged per wave as
-  // [32 rows][64 columns] f32, then read back row-wise so that every lane handles 8 consecutive columns of
-  // one row: 16-byte (bf16) / 32-byte (f32) global stores, 128..256 contiguous bytes per row, and the
-  // bias / residual / pre-activation operands are read with the same coalesced shape.
   float* stage = (float*)smem + w * (32 * G_SP);
 #pragma unroll
-  for (int tp = 0; tp < (NT + 1) / 2; ++tp) {
-    const int t0 = 2 * tp, t1 = 2 * tp + 1;
+  for (int tp = 0; tp < (NT + 1) / 2; ++tp)
+    epilogue_pair<EPI>(stage, acc[2 * tp], acc[(2 * tp + 1 < NT) ? 2 * tp + 1 : 2 * tp], 2 * tp + 1 < NT,
+                       (long)m0 + 32 * w, n0 + 64 * tp, M, N, e);
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_skinny: Y[M,N] = A[M,K] * W[N,K]^T for K in (192, 208] (the model dim).
+//  * the A fragments of a wave's 32 rows (13 k-steps) are loaded from global memory straight into
+//    REGISTERS once and stay there; the workgroup walks its range of output columns 64 at a time,
+//    streaming the matching W rows through one 32 KB LDS panel;
+//  * the product is formed TRANSPOSED (W rows on the MFMA row index, tokens on the lane), and the W rows
+//    of a chunk are permuted inside the panel so that every lane ends up holding, for ITS token, 4 groups
+//    of 8 consecutive output columns: the epilogue (bias, GELU, GELU', bf16 conversion) runs on the
+//    accumulators in registers and stores 16 bytes per lane -- no LDS round trip for the output.
+//  grid = (ceil(M/128), column splits).
+// ------------------------------------------------------------------------------------------
+constexpr int SK_KS = 13;                 // k-steps held in registers (K <= 208)
+constexpr int SK_WBYTES = 4 * 64 * 128;   // one W chunk: 4 k-blocks of [64 rows][64 k] bf16 images
+
+// panel row of output column c (0..63) of a chunk: tile t = (c>>2)&1, MFMA row i = 8(c>>4) + 4((c>>3)&1) + (c&3).
+// Accumulator register r of tile t on lane-half h then holds column 16(r>>2) + 8h + 4t + (r&3).
+SCM_DEV int sk_panel_row(int c) { return 32 * ((c >> 2) & 1) + 8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3); }
+
+template <bool A_F32, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_skinny_kernel(const void* __restrict__ Ap, long lda,
+                                                             const bf16* __restrict__ W, long ldw, int M, int N,
+                                                             int K, GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  constexpr uint32_t AE = A_F32 ? 4 : 2;
+
+  // Work items = (128-row tile, 64-column chunk) pairs in row-major order, dealt out in equal contiguous
+  // ranges to a grid that just fills the machine: no tail round, no CU with twice the work of another.
+  const int nchunks = (N + 63) >> 6;
+  const long total = (long)((M + G_BM - 1) / G_BM) * nchunks;
+  const int it_lo = (int)(total * blockIdx.x / gridDim.x), it_hi = (int)(total * (blockIdx.x + 1) / gridDim.x);
+  if (it_lo >= it_hi) return;
+
+  // every global access goes through a bounds-checked buffer resource: out-of-range lanes pass BUF_OOB
+  const brsrc rA = make_rsrc(Ap, (uint32_t)(((long)(M - 1) * lda + K) * AE));
+  const brsrc rW = make_rsrc(W, (uint32_t)(((long)(N - 1) * ldw + K) * 2));
+  const brsrc rO0 = make_rsrc(e.out0, (uint32_t)(((long)(M - 1) * e.ldo0 + N) * 2));
+  const brsrc rO1 = make_rsrc(EPI == EPI_GELU_DUAL ? e.out1 : e.out0,
+                              (uint32_t)(((long)(M - 1) * (EPI == EPI_GELU_DUAL ? e.ldo1 : e.ldo0) + N) * 2));
+  const brsrc rP = make_rsrc(EPI == EPI_DGELU ? (const void*)e.pre : (const void*)W,
+                             EPI == EPI_DGELU ? (uint32_t)(((long)(M - 1) * e.ldp + N) * 2) : 0u);
+  const bool has_bias = (EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) && e.bias != nullptr;
+  const brsrc rB = make_rsrc(has_bias ? (const void*)e.bias : (const void*)W, has_bias ? (uint32_t)N * 4 : 0u);
+
+  char* Ws = smem;
+  int roff[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      stage[acc_row(r, half) * G_SP + (l & 31)] = acc[t0][r];
-      if (t1 < NT) stage[acc_row(r, half) * G_SP + 32 + (l & 31)] = acc[t1][r];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int ch = l & 7;
-    const int col = n0 + 64 * tp + 8 * ch;
-    const bool col_ok = (t1 < NT || ch < 4) && col < N;
-    float bias[8];
+  for (int i = 0; i < 4; ++i) roff[i] = img_off(l & 31, 16 * i + 8 * half);
+
+  // W staging: thread (wr = tid>>2, q = tid&3) moves 16-byte k-chunks q, q+4, .., q+24 of W row n0 + wr
+  const int kc = K >> 3;
+  const int wr = tid >> 2, q = tid & 3;
+  const int prow = sk_panel_row(wr);
+  const int wdst0 = img_off(prow, 8 * q), wdst1 = img_off(prow, 8 * (q + 4));
+  const uint32_t wsrc = (uint32_t)(wr * ldw + 8 * q) * 2;
+  u32x4 wst[7];
+  auto load_w = [&](int it) {   // items past the range read the rows from N on: zeros
+    const int n0 = it < it_hi ? 64 * (it % nchunks) : N;
+    const uint32_t base = n0 + wr < N ? wsrc + (uint32_t)(n0 * ldw) * 2 : BUF_OOB;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bias[j] = 0.f;
-    if ((EPI == EPI_F32_BIAS_RES || EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) && e.bias && col_ok) {
-      const f32x4 b0 = *(const f32x4*)(e.bias + col), b1 = *(const f32x4*)(e.bias + col + 4);
+    for (int j = 0; j < 6; ++j) wst[j] = buf_load16(rW, base + 64 * j);        // k chunks q+4j <= 23 < kc
+    wst[6] = buf_load16(rW, (q + 24 < kc) ? base + 64 * 6 : BUF_OOB);
+  };
+  auto store_w = [&]() {   // chunks >= kc carry zeros: the panel's k tail is cleared on every refill
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { bias[j] = b0[j]; bias[4 + j] = b1[j]; }
-    }
+    for (int j = 0; j < 7; ++j) *(u32x4*)(Ws + (j >> 1) * (64 * 128) + ((j & 1) ? wdst1 : wdst0)) = wst[j];
+  };
+  {  // k chunks 28..31 of the last k-block are never written by store_w: clear them once
+    *(u32x4*)(Ws + 3 * (64 * 128) + img_off(wr, 8 * (4 + q))) = u32x4{0, 0, 0, 0};
+  }
+
+  // Software pipeline over the items: while item i is multiplied, the W chunk of item i+1 sits in registers and
+  // the loads of item i+2's chunk are issued before the epilogue's stores.
+  load_w(it_lo);
+  store_w();
+  __syncthreads();
+  load_w(it_lo + 1);
+
+  // A fragments of a row tile: global -> registers (lane: row l&31, k = 16 ks + 8 half .. +7).  Issued right
+  // after the last MFMA of the previous tile, so the latency hides behind that item's epilogue.
+  bf16x8 af[SK_KS];
+  long row = 0;
+  auto load_a = [&](int tile) {
+    row = (long)tile * G_BM + 32 * w + (l & 31);
+    const uint32_t base = (row < M ? (uint32_t)(row * lda) * AE : BUF_OOB) + 8 * half * AE;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int rl = 8 * pass + (l >> 3);
-      const long row = m0 + 32 * w + rl;
-      if (!col_ok || row >= M) continue;
-      const f32x4 a0 = *(const f32x4*)(stage + rl * G_SP + 8 * ch);
-      const f32x4 a1 = *(const f32x4*)(stage + rl * G_SP + 8 * ch + 4);
-      float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    for (int ks = 0; ks < SK_KS; ++ks) {
+      // k = 16 ks + 8 half < K for every ks < 12 (K > 192); the last step's upper half exists only for K = 208
+      const uint32_t off = (ks < SK_KS - 1 || half == 0 || K > 200) ? base + 16 * ks * AE : BUF_OOB;
+      if (A_F32) {
+        const f32x4 x0 = as_f32x4(buf_load16(rA, off)), x1 = as_f32x4(buf_load16(rA, off + 16));
+        bf16x8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += bias[j];
-      if (EPI == EPI_BF16 || EPI == EPI_BF16_BIAS) {
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-        *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
-      } else if (EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES) {
-        if (EPI == EPI_F32_BIAS_RES && e.resid) {
-          const f32x4 r0 = *(const f32x4*)(e.resid + row * e.ldr + col);
-          const f32x4 r1 = *(const f32x4*)(e.resid + row * e.ldr + col + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
-        }
-        float* op = (float*)e.out0 + row * e.ldo0 + col;
-        *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else if (EPI == EPI_GELU_DUAL) {
-        bf16x8 o, g;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { o[j] = (bf16)v[j]; g[j] = (bf16)gelu_erf(v[j]); }
-        *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
-        *(bf16x8*)((bf16*)e.out1 + row * e.ldo1 + col) = g;
-      } else if (EPI == EPI_DGELU) {
-        const bf16x8 pv = *(const bf16x8*)(e.pre + row * e.ldp + col);
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * gelu_erf_grad((float)pv[j]));
-        *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
+        for (int j = 0; j < 4; ++j) { v[j] = (bf16)x0[j]; v[4 + j] = (bf16)x1[j]; }
+        af[ks] = v;
+        if (ks & 1) __builtin_amdgcn_sched_barrier(0);   // at most 4 raw f32 loads (16 registers) in flight
+      } else {
+        af[ks] = as_bf16x8(buf_load16(rA, off));
       }
     }
-    __builtin_amdgcn_wave_barrier();
+  };
+  load_a(it_lo / nchunks);
+  for (int it = it_lo; it < it_hi; ++it) {
+    const int tile = it / nchunks, c = it - tile * nchunks;
+    const long orow = row;          // the epilogue below still belongs to this item's tile
+    f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+    for (int ks = 0; ks < SK_KS; ++ks) {   // 26 independent LDS reads feeding 26 MFMAs
+      const char* blk = Ws + (ks >> 2) * (64 * 128);
+      acc0 = mfma32(*(const bf16x8*)(blk + roff[ks & 3]), af[ks], acc0);
+      acc1 = mfma32(*(const bf16x8*)(blk + 4096 + roff[ks & 3]), af[ks], acc1);
+    }
+    if (c + 1 == nchunks && it + 1 < it_hi) load_a(tile + 1);
+    __syncthreads();                       // every wave is done reading this item's W panel
+    store_w();                             // next item's chunk (loaded one iteration ago)
+    load_w(it + 2);
+    // ---- epilogue on registers: lane = token `orow`, group g = columns col .. col+7; straight-line
+    const int colb = 64 * c + 8 * half;
+    uint32_t oo[4], bias_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = colb + 16 * g;
+      oo[g] = (orow < M && col < N) ? (uint32_t)col : BUF_OOB;   // column part; row part added per tensor
+      bias_off[g] = (uint32_t)col * 4;
+    }
+    u32x4 pv[4];
+    if (EPI == EPI_DGELU) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pv[g] = buf_load16(rP, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldp) + oo[g]) * 2);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[8] = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3],
+                    acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+      if (EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) {   // a null bias reads zeros
+        const f32x4 b0 = as_f32x4(buf_load16(rB, bias_off[g])), b1 = as_f32x4(buf_load16(rB, bias_off[g] + 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+      }
+      bf16x8 o;
+      if (EPI == EPI_DGELU) {
+        const bf16x8 pb = as_bf16x8(pv[g]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * gelu_erf_grad((float)pb[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+      }
+      buf_store16(rO0, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo0) + oo[g]) * 2, as_u32x4(o));
+      if (EPI == EPI_GELU_DUAL) {
+        bf16x8 gl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gl[j] = (bf16)gelu_erf(v[j]);
+        buf_store16(rO1, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo1) + oo[g]) * 2, as_u32x4(gl));
+      }
+    }
+    __syncthreads();                       // next item's chunk visible
   }
 }
 
@@ -384,9 +570,30 @@ static hipError_t launch_gemm(const void* A, long lda, const bf16* W, long ldw, 
 }
 
 template <bool A_F32, int EPI>
+static hipError_t launch_skinny(const void* A, long lda, const bf16* W, long ldw, int M, int N, int K, GemmEpi e,
+                                hipStream_t s) {
+  const long total = (long)((M + G_BM - 1) / G_BM) * ((N + 63) / 64);
+  // 3 workgroups per CU are resident (register bound): one full wave of them, each with an equal item range
+  static const int force = getenv("SCM_SK_GRID") ? atoi(getenv("SCM_SK_GRID")) : 0;
+  long grid = force > 0 ? force : 768;
+  if (grid > total) grid = total;
+  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s);
+  hipLaunchKernelGGL((gemm_skinny_kernel<A_F32, EPI>), dim3((unsigned)grid), dim3(256), SK_WBYTES, s, A, lda, W, ldw,
+                     M, N, K, e);
+  return hipGetLastError();
+}
+
+template <bool A_F32, int EPI>
 static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, int M, int N, int K, GemmEpi e,
                               hipStream_t s) {
-  // N = 200 -> one 224-wide tile; N in {640, 800, 1920} -> 160-wide tiles; otherwise 128-wide.
+  // K <= 208 (the model dim) with a wide output: A-in-registers kernel.
+  // Otherwise N = 200 -> one 224-wide tile; N in {640, 800, 1920} -> 160-wide tiles; else 128-wide.
+  const long lim = 1l << 31;   // the A-in-registers kernel addresses its operands with 32-bit byte offsets
+  const bool fits = (long)M * lda * 4 < lim && (long)N * ldw * 2 < lim && (long)M * e.ldo0 * 2 < lim &&
+                    (long)M * e.ldo1 * 2 < lim && (long)M * e.ldp * 2 < lim;
+  if (fits && K > 16 * (SK_KS - 1) && K <= 16 * SK_KS && N >= 256 &&
+      (EPI == EPI_BF16 || EPI == EPI_BF16_BIAS || EPI == EPI_GELU_DUAL || EPI == EPI_DGELU))
+    return launch_skinny<A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
   if (N <= 224) return launch_gemm<7, A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
   if (N % 160 == 0) return launch_gemm<5, A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
   return launch_gemm<4, A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);

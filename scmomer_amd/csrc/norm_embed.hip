@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      long T, int D, float* __restrict__ dx,
-                                                     float* __restrict__ partial) {
+                                                     bf16* __restrict__ dx_b, float* __restrict__ partial) {
   __shared__ float red[4][3][256];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         ar[j] += r[j];
       }
       *(f32x4*)(dx + t * D + 4 * l) = o;
+      if (dx_b) *(bf16x4*)(dx_b + t * D + 4 * l) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
     }
   }
 #pragma unroll
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ W, long T, int D, int C, int relu,
-                                                       float* __restrict__ dx, float* __restrict__ partial) {
+                                                       float* __restrict__ dx, bf16* __restrict__ dx_b,
+                                                       float* __restrict__ partial) {
   extern __shared__ float red[];  // [4][(2 + C) * 256 + 64]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         ab[j] += d[j];
       }
       *(f32x4*)(dx + t * D + 4 * l) = o;
+      if (dx_b) *(bf16x4*)(dx_b + t * D + 4 * l) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
     }
   }
   const int stride = (2 + C) * 256 + 64;
@@ -363,10 +366,10 @@ hipError_t ln_fwd(const float* x, const float* g, const float* b, long T, int D,
 }
 int ln_bwd_blocks(long T) { long b = (T + 63) / 64; return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024); }
 hipError_t ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                  const float* dres, long T, int D, float* dx, float* partial, hipStream_t s) {
+                  const float* dres, long T, int D, float* dx, void* dx_b, float* partial, hipStream_t s) {
   Traced tr(K_LN_BWD, 0, s);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_blocks(T)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, T, D, dx,
-                     partial);
+                     (bf16*)dx_b, partial);
   return hipGetLastError();
 }
 hipError_t head_fwd(const float* x, const float* g, const float* b, const float* W, const float* bias, long T, int D,
@@ -378,11 +381,11 @@ hipError_t head_fwd(const float* x, const float* g, const float* b, const float*
 }
 hipError_t head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
                     const float* rstd, const float* gamma, const float* beta, const float* W, long T, int D, int C,
-                    int relu, float* dx, float* partial, hipStream_t s) {
+                    int relu, float* dx, void* dx_b, float* partial, hipStream_t s) {
   size_t lds = (size_t)4 * ((2 + C) * 256 + 64) * sizeof(float);
   Traced tr(K_HEAD_BWD, 0, s);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(ln_bwd_blocks(T)), dim3(256), lds, s, dout, denc, out, x, mean, rstd, gamma,
-                     beta, W, T, D, C, relu, dx, partial);
+                     beta, W, T, D, C, relu, dx, (bf16*)dx_b, partial);
   return hipGetLastError();
 }
 hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, int hi, float* out, int accumulate,

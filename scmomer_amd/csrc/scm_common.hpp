@@ -120,9 +120,45 @@ SCM_DEV bf16x8 img_row_frag(const char* img, int row_base, int kbase) {
   return *(const bf16x8*)(img + img_off(row, kbase + 8 * (l >> 5)));
 }
 
-SCM_DEV float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// ---- raw buffer access: the hardware bounds check replaces per-lane branches around global memory ops.
+// Loads at a byte offset >= the resource's size return 0 and stores there are dropped, so a lane that is out
+// of range simply passes BUF_OOB: the instruction stream stays straight-line and the compiler can keep many
+// loads in flight with exact s_waitcnt counts.  Resources cover less than 2 GiB (32-bit offsets).
+typedef __amdgpu_buffer_rsrc_t brsrc;
+constexpr uint32_t BUF_OOB = 0x80000000u;   // stays out of range when a small immediate offset is added
+SCM_DEV brsrc make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+SCM_DEV u32x4 buf_load16(brsrc r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
+SCM_DEV void buf_store16(brsrc r, uint32_t off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0); }
+SCM_DEV bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+SCM_DEV f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+SCM_DEV u32x4 as_u32x4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 rounding level): one rcp, one exp2, five fma.
+// libm's erff costs ~50 VALU instructions per element, which made the GELU epilogues VALU-bound.
+// Returns erf(|x|/sqrt2) pieces shared by gelu and its derivative: phi = exp(-x^2/2).
+SCM_DEV void gelu_parts(float x, float& cdf, float& pdf) {
+  const float ax = fabsf(x) * 0.70710678118654752f;           // |x| / sqrt(2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float e = exp2_fast(-ax * ax * LOG2E);                // exp(-x^2/2)
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erfa = 1.f - p * t * e;                          // erf(|x|/sqrt2)
+  cdf = 0.5f * (1.f + copysignf(erfa, x));                     // Phi(x)
+  pdf = 0.3989422804014327f * e;                               // phi(x)
+}
+SCM_DEV float gelu_erf(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 SCM_DEV float gelu_erf_grad(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return cdf + x * pdf;
 }
 
 }  // namespace scm

@@ -86,12 +86,12 @@ hipError_t ln_fwd(const float* x, const float* g, const float* b, long T, int D,
                   hipStream_t s);
 int ln_bwd_blocks(long T);
 hipError_t ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                  const float* dres, long T, int D, float* dx, float* partial, hipStream_t s);
+                  const float* dres, long T, int D, float* dx, void* dx_b, float* partial, hipStream_t s);
 hipError_t head_fwd(const float* x, const float* g, const float* b, const float* W, const float* bias, long T, int D,
                     int C, int relu, float* enc, float* out, float* mean, float* rstd, hipStream_t s);
 hipError_t head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
                     const float* rstd, const float* gamma, const float* beta, const float* W, long T, int D, int C,
-                    int relu, float* dx, float* partial, hipStream_t s);
+                    int relu, float* dx, void* dx_b, float* partial, hipStream_t s);
 hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, int hi, float* out, int accumulate,
                          hipStream_t s);
 

@@ -105,15 +105,17 @@ def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool):
+def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool, with_bf16: bool = False):
+    """-> dx f32, or (dx, dx rounded to bf16) when with_bf16"""
     _req(dy, F32, "dy")
     d = x.shape[-1]
     t = x.numel() // d
     dx = torch.empty_like(x)
+    dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if with_bf16 else None
     ws = torch.empty(lib.scm_ln_bwd_ws_floats(t, d), dtype=F32, device=x.device)
-    check(lib.scm_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), t, d, _p(dx), _p(ws), _p(dgamma),
-                         _p(dbeta), _p(dres_colsum), int(accumulate), _stream()), "scm_ln_bwd")
-    return dx
+    check(lib.scm_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), t, d, _p(dx), _p(dxb), _p(ws),
+                         _p(dgamma), _p(dbeta), _p(dres_colsum), int(accumulate), _stream()), "scm_ln_bwd")
+    return (dx, dxb) if with_bf16 else dx
 
 
 # ----------------------------------------------------------------------------- linear products
@@ -217,16 +219,19 @@ def head_fwd(x, gamma, beta, w, bias, relu: bool, want_enc: bool, want_out: bool
     return enc, out, mean, rstd
 
 
-def head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, w, relu: bool, dgamma, dbeta, dw, db, accumulate: bool):
+def head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, w, relu: bool, dgamma, dbeta, dw, db, accumulate: bool,
+             with_bf16: bool = False):
+    """-> dx f32, or (dx, dx rounded to bf16) when with_bf16"""
     d = x.shape[-1]
     t = x.numel() // d
     c = w.shape[0] if (w is not None and dout is not None) else 0
     dx = torch.empty_like(x)
+    dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if with_bf16 else None
     ws = torch.empty(lib.scm_head_bwd_ws_floats(t, d, c), dtype=F32, device=x.device)
     check(lib.scm_head_bwd(_p(dout), _p(denc), _p(out), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
-                           _p(w) if c else None, t, d, c, int(relu), _p(dx), _p(ws), _p(dgamma), _p(dbeta),
+                           _p(w) if c else None, t, d, c, int(relu), _p(dx), _p(dxb), _p(ws), _p(dgamma), _p(dbeta),
                            _p(dw) if c else None, _p(db) if c else None, int(accumulate), _stream()), "scm_head_bwd")
-    return dx
+    return (dx, dxb) if with_bf16 else dx
 
 
 # ----------------------------------------------------------------------------- per-kernel timing

@@ -155,8 +155,10 @@ def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[tor
 
 
 def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
-             dres: Optional[torch.Tensor], need_dx: bool):
-    """dy: f32 [T,D] gradient of the branch output.  Returns (dx f32 [T,D] or None, grads dict).
+             dres: Optional[torch.Tensor], need_dx: bool, dy_b: Optional[torch.Tensor] = None, want_b: bool = False):
+    """dy: f32 [T,D] gradient of the branch output (dy_b: the same rounded to bf16, when the producer already
+    wrote it; the matrix products read that copy).  Returns (dx f32 [T,D] or None, grads dict), dx being a
+    (dx, dx_bf16) pair when want_b and ln.
     With ln: dx = dres + LN'(dh); grads['bo'] is taken from column sums of dy inside the LN kernel."""
     b, n, d = tp.shape
     t = b * n
@@ -166,12 +168,12 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
     g: Dict[str, torch.Tensor] = {}
     if need["wo"]:
         g["wo"] = torch.empty((d, inner), dtype=F32, device=dev)
-        ops.wgrad(tp.o.view(t, inner), dy, g["wo"], None, True, False)
+        ops.wgrad(tp.o.view(t, inner), dy if dy_b is None else dy_b, g["wo"], None, True, False)
     need_qkv_w = need["wq"] or need["wk"] or need["wv"] or need["bq"]
     need_dh = need_dx or (ln and (need["g1"] or need["b1"]))
     if need_qkv_w or need_dh:
         do = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=dev)
-        ops.gemm_nt(ops.EPI_BF16, dy, w["wo_t"], out0=do.view(t, inner))
+        ops.gemm_nt(ops.EPI_BF16, dy if dy_b is None else dy_b, w["wo_t"], out0=do.view(t, inner))
         dqkv = torch.empty((b, n, 3, heads, ops.DIM_HEAD), dtype=BF16, device=dev)
         q, k, v = _qkv_views(tp.qkv)
         dq, dk, dv = _qkv_views(dqkv)
@@ -192,7 +194,7 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
             g["g1"] = torch.empty(d, dtype=F32, device=dev)
             g["b1"] = torch.empty(d, dtype=F32, device=dev)
             g["bo"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
-            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g1"], dres, g["g1"], g["b1"], g["bo"], False)
+            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g1"], dres, g["g1"], g["b1"], g["bo"], False, want_b)
         else:
             dx = dh
     if need["bo"] and g.get("bo") is None:
@@ -232,7 +234,8 @@ def ffn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torc
 
 
 def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
-            dres: Optional[torch.Tensor], need_dx: bool):
+            dres: Optional[torch.Tensor], need_dx: bool, dy_b: Optional[torch.Tensor] = None, want_b: bool = False):
+    """as attn_bwd, for the FeedForward branch"""
     b, n, d = tp.shape
     t = b * n
     f = p["w1"].shape[0]
@@ -240,11 +243,11 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
     g: Dict[str, torch.Tensor] = {}
     if need["w2"]:
         g["w2"] = torch.empty((d, f), dtype=F32, device=dev)
-        ops.wgrad(tp.act, dy, g["w2"], None, True, False)
+        ops.wgrad(tp.act, dy if dy_b is None else dy_b, g["w2"], None, True, False)
     need_dh = need_dx or (ln and (need["g2"] or need["b2"]))
     if need["w1"] or need["c1"] or need_dh:
         dpre = torch.empty((t, f), dtype=BF16, device=dev)
-        ops.gemm_nt(ops.EPI_DGELU, dy, w["w2_t"], out0=dpre, pre=tp.pre)
+        ops.gemm_nt(ops.EPI_DGELU, dy if dy_b is None else dy_b, w["w2_t"], out0=dpre, pre=tp.pre)
         if need["w1"] or need["c1"]:
             g["w1"] = torch.empty((f, d), dtype=F32, device=dev)
             g["c1"] = torch.empty(f, dtype=F32, device=dev)
@@ -257,7 +260,7 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
             g["g2"] = torch.empty(d, dtype=F32, device=dev)
             g["b2"] = torch.empty(d, dtype=F32, device=dev)
             g["c2"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
-            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g2"], dres, g["g2"], g["b2"], g["c2"], False)
+            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g2"], dres, g["g2"], g["b2"], g["c2"], False, want_b)
         else:
             dx = dh
     if need["c2"] and g.get("c2") is None:
@@ -365,13 +368,14 @@ class _StackFn(torch.autograd.Function):
                               None if want_out else dout.to(F32).reshape(t, d),
                               out, x, mean, rstd, spec.norm_w, spec.norm_b, spec.head_w if want_out else None,
                               spec.head_relu, gg, gb, gw.view(-1, d) if want_out else None,
-                              gbias.view(-1) if want_out else None, False)
-            dx = dx.reshape(t, d)
+                              gbias.view(-1) if want_out else None, False, True)
+            dx, dxb = dx[0].reshape(t, d), dx[1].reshape(t, d)
             grads[(-2, "norm_w")], grads[(-2, "norm_b")] = gg, gb
             if want_out:
                 grads[(-2, "head_w")], grads[(-2, "head_b")] = gw, gbias
         else:
             dx = dout.to(F32).reshape(-1, dout.shape[-1])
+            dxb = None
         for li in range(nl - 1, first - 1, -1):
             ap, fp = spec.layers[li]
             aw, fw = spec.cache.attn(li, ap), spec.cache.ffn(li, fp)
@@ -380,17 +384,21 @@ class _StackFn(torch.autograd.Function):
             nf = {k: need_p.get((li, k), False) for k in FFN_KEYS}
             na = {k: need_p.get((li, k), False) for k in ATTN_KEYS}
             attn_needs_any = any(na.values())
-            dx1, gf = ffn_bwd(dx, ft, fp, fw, nf, ln=True, dres=dx, need_dx=(not lowest) or attn_needs_any)
+            # the LayerNorm-backward kernels also emit their result rounded to bf16: the operand of the next
+            # data- and weight-gradient products
+            dx1, gf = ffn_bwd(dx, ft, fp, fw, nf, ln=True, dres=dx, need_dx=(not lowest) or attn_needs_any,
+                              dy_b=dxb, want_b=True)
             for k, v in gf.items():
                 if v is not None:
                     grads[(li, k)] = v
             if dx1 is None:
                 break
-            dx0, ga = attn_bwd(dx1, at, ap, aw, na, ln=True, dres=dx1, need_dx=not lowest)
+            dx1, dx1b = dx1
+            dx0, ga = attn_bwd(dx1, at, ap, aw, na, ln=True, dres=dx1, need_dx=not lowest, dy_b=dx1b, want_b=True)
             for k, v in ga.items():
                 if v is not None:
                     grads[(li, k)] = v
-            dx = dx0
+            dx, dxb = dx0 if dx0 is not None else (None, None)
         d_inp = None
         if first == 0 and need_inp and dx is not None:
             if ctx.tokens is not None:

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-op microbenchmark at the S1 step's shapes (B=3, N=16906): time, TFLOP/s and GB/s of algorithmic bytes.
+usage (GPU box): python tools/kbench.py [filter]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scmomer_amd import ops
+T, D, H, F = 3 * 16906, 200, 10, 800
+INNER = 640
+dev = "cuda"
+bf, f32 = torch.bfloat16, torch.float32
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e-3
+
+def rnd(*shape, dtype=bf): return (torch.randn(*shape, device=dev) * 0.5).to(dtype)
+cases = []
+def gemm_case(name, epi, a_dtype, K, N, out_dtype, extra=None, nbytes=None):
+    a = rnd(T, K, dtype=a_dtype); w = rnd(N, K); out0 = torch.empty(T, N, dtype=out_dtype, device=dev)
+    kw = dict(out0=out0)
+    by = T * K * a.element_size() + T * N * out0.element_size()
+    if extra == "gelu": kw.update(out1=torch.empty(T, N, dtype=bf, device=dev), bias=rnd(N, dtype=f32)); by += T * N * 2
+    if extra == "dgelu": kw.update(pre=rnd(T, N)); by += T * N * 2
+    if extra == "res": kw.update(bias=rnd(N, dtype=f32), resid=rnd(T, N, dtype=f32)); by += T * N * 4
+    cases.append((name, lambda: ops.gemm_nt(epi, a, w, **kw), 2.0 * T * K * N, by))
+gemm_case("qkv       K200 N1920 bf16", ops.EPI_BF16, bf, 200, 1920, bf)
+gemm_case("ffn1+gelu K200 N800  bf16x2", ops.EPI_GELU_DUAL, bf, 200, 800, bf, "gelu")
+gemm_case("dO        K200 N640  f32A", ops.EPI_BF16, f32, 200, 640, bf)
+gemm_case("dgelu     K200 N800  f32A", ops.EPI_DGELU, f32, 200, 800, bf, "dgelu")
+gemm_case("outproj   K640 N200  f32+res", ops.EPI_F32_BIAS_RES, bf, 640, 200, f32, "res")
+gemm_case("ffn2      K800 N200  f32+res", ops.EPI_F32_BIAS_RES, bf, 800, 200, f32, "res")
+gemm_case("dh(qkv)   K1920 N200 f32", ops.EPI_F32, bf, 1920, 200, f32)
+gemm_case("dh(ffn)   K800 N200  f32", ops.EPI_F32, bf, 800, 200, f32)
+def wgrad_case(name, P, qdtype, trans, bias):
+    pm = rnd(T, P); qm = rnd(T, 200, dtype=qdtype)
+    g = torch.zeros((200, P) if trans else (P, 200), device=dev); b = torch.zeros(P, device=dev) if bias else None
+    cases.append((name, lambda: ops.wgrad(pm, qm, g, b, trans, False), 2.0 * T * P * 200, T * P * 2 + T * 200 * qm.element_size()))
+wgrad_case("wgrad P1920 bf16", 1920, bf, False, False)
+wgrad_case("wgrad P800 bf16 +bias", 800, bf, False, True)
+wgrad_case("wgrad P800 f32 trans", 800, f32, True, False)
+wgrad_case("wgrad P640 f32 trans", 640, f32, True, False)
+filt = sys.argv[1] if len(sys.argv) > 1 else ""
+for name, fn, flops, by in cases:
+    if filt and filt not in name: continue
+    dt = timeit(fn)
+    print(f"{name:32s} {dt*1e6:8.1f} us  {flops/dt/1e12:7.1f} TFLOP/s  {by/dt/1e12:5.2f} TB/s")
