@@ -94,6 +94,7 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
 
+    from scmomer_amd import dist as sdist
     from scmomer_amd import ops, s1, stack
     torch.manual_seed(2024 + rank)
     model = build_model(device)
@@ -103,6 +104,7 @@ def main():
     loss_fn = torch.nn.CrossEntropyLoss(ignore_index=6, reduction="mean")
     for p in params:                       # static gradient buffers: micro-steps accumulate into them
         p.grad = torch.zeros_like(p)
+    averager = sdist.GradientAverager(params)   # one flat bucket, one all-reduce per optimizer step
 
     # each rank owns its own shard of synthetic cells (resident in HBM before timing starts)
     n_batches = 4
@@ -120,14 +122,7 @@ def main():
     def sync_step():
         """every grad_acc micro-steps: average gradients over ranks (what DDP's reducer does on the sync
         step, s1_pretrain_rna.py:299-305), clip, Adam, zero"""
-        if world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
-            flat.div_(world)
-            off = 0
-            for p in params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+        averager.average_()
         torch.nn.utils.clip_grad_norm_(params, int(1e2))
         opt.step()
         opt.zero_grad(set_to_none=False)
@@ -171,10 +166,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = sdist.max_over_ranks(dt, device)
     final_loss = float(static_loss.item()) * args.grad_acc
 
     # Per-kernel durations: HIP events on the launch stream around each launch of the traced kernel, taken on

@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the package has no fallback path: make sure the HIP library exists (hipcc cross-compiles without a GPU)
+    so = os.path.join(ROOT, "scmomer_amd", "libscmomer_hip.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "scmomer_amd", "csrc"), "-j8"], check=True)
 
 
 @pytest.fixture(scope="session")
