@@ -7,8 +7,8 @@ cross-entropy with ignore_index, backward; every `--grad-acc` steps the gradient
 (DDP over RCCL when --gpus > 1), clipped and applied with Adam, exactly as the reference's loop
 (s1_pretrain_rna.py:294-305).  Cells are sharded across ranks; per-GPU work is fixed (weak scaling).
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel, timed with HIP events on
-its launch stream inside the timed region; `cpu_baseline` is the CPU oracle (a port of the
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (largest share of the step), timed
+with HIP events on its launch stream; `cpu_baseline` is the CPU oracle (a port of the
 reference path, validated against it) timed on this host on a bounded sample.
 """
 import argparse
@@ -26,7 +26,7 @@ N_GENES = 16906
 BATCH = 3
 FLOP_FWD_BWD_PER_CELL = 853.50e9   # algorithmic GEMM-term FLOPs, forward+backward, one cell
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA
-DOMINANT_KERNEL = os.environ.get("SCM_BENCH_TRACE_KERNEL", "favor_apply_bwd_k")
+PEAK_HBM_GBS = 8000.0              # MI355X HBM3E
 
 
 def parse():
@@ -126,12 +126,12 @@ def main():
         torch.nn.utils.clip_grad_norm_(params, int(1e2))
         opt.step()
         opt.zero_grad(set_to_none=False)
+        stack.refresh_weights(model)       # bf16 operand copies of the updated weights (in place, outside the graph)
 
-    # The micro-step is launch-bound when driven from Python (about 300 kernel launches), so it is captured
-    # once into a HIP graph and replayed; the bf16 weight copies are refreshed inside the graph.
+    # The micro-step is launch-bound when driven from Python (about 250 kernel launches), so it is captured
+    # once into a HIP graph and replayed; the bf16 weight copies it reads are refreshed after each Adam step.
     graph = None
     if not args.eager:
-        stack.WeightCache.enabled = False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -169,12 +169,13 @@ def main():
     dt = sdist.max_over_ranks(dt, device)
     final_loss = float(static_loss.item()) * args.grad_acc
 
-    # Per-kernel durations: HIP events on the launch stream around each launch of the traced kernel, taken on
-    # a few eager micro-steps right after the timed region (event pairs cannot be read back from inside a
-    # replayed graph; the kernels and their inputs are the same).
+    # Per-kernel durations: HIP events on the launch stream around every launch, taken on a few eager
+    # micro-steps right after the timed region (event pairs cannot be read back from inside a replayed graph;
+    # the kernels, their inputs and their launch configurations are the same).
     ops.trace_collect()
-    ops.trace_enable("all" if args.trace_all else DOMINANT_KERNEL)
-    for i in range(3):
+    ops.trace_enable("all")
+    traced_steps = 3
+    for i in range(traced_steps):
         static_tok.copy_(data[i % n_batches])
         micro_step()
     torch.cuda.synchronize()
@@ -184,20 +185,31 @@ def main():
     if rank == 0:
         cells = world * args.batch * args.steps
         value = cells / dt
-        ms, fl, cnt = trace.get(DOMINANT_KERNEL, (0.0, 0.0, 0))
-        roof = None
-        if cnt:
-            ach = fl / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                    "avg_launch_ms": ms / cnt, "launches": cnt,
-                    "whole_step_tflops": value / world * FLOP_FWD_BWD_PER_CELL / 1e12,
-                    "whole_step_frac": value / world * FLOP_FWD_BWD_PER_CELL / 1e12 / PEAK_BF16_TFLOPS}
+        # the dominant kernel = the traced kernel with the largest share of the step
+        dominant = os.environ.get("SCM_BENCH_TRACE_KERNEL") or max(trace, key=lambda k: trace[k][0])
+        ms, fl, cnt, by = trace[dominant]
+        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # FLOP per byte where the two roofs meet
+        bound = "mfma" if by <= 0 or fl / by >= ridge else "hbm"
+        tflops, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        roof = {"bound": bound, "kernel": dominant,
+                "achieved": tflops if bound == "mfma" else gbs,
+                "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": tflops / PEAK_BF16_TFLOPS if bound == "mfma" else gbs / PEAK_HBM_GBS,
+                "traffic": None,
+                "avg_launch_ms": ms / cnt, "launches_per_step": cnt / traced_steps,
+                "algorithmic_bytes_per_launch": by / cnt, "algorithmic_flops_per_launch": fl / cnt,
+                "tflops": tflops, "gbs": gbs, "share_of_kernel_time": ms / sum(v[0] for v in trace.values()),
+                "whole_step_tflops": value / world * FLOP_FWD_BWD_PER_CELL / 1e12,
+                "whole_step_frac_of_mfma_peak": value / world * FLOP_FWD_BWD_PER_CELL / 1e12 / PEAK_BF16_TFLOPS}
+        kernels = {k: {"ms_per_step": round(m_ / traced_steps, 4), "launches_per_step": c_ / traced_steps,
+                       "tflops": round(f_ / (m_ * 1e-3) / 1e12, 1), "gbs": round(b_ / (m_ * 1e-3) / 1e9, 1)}
+                   for k, (m_, f_, c_, b_) in sorted(trace.items(), key=lambda kv: -kv[1][0])}
         if args.trace_all:
             tot = sum(v[0] for v in trace.values())
-            for k, (m_, f_, c_) in sorted(trace.items(), key=lambda kv: -kv[1][0]):
-                print(f"  {k:22s} {m_:9.2f} ms {100 * m_ / tot:5.1f}%  launches {c_:5d}  "
-                      f"{(f_ / (m_ * 1e-3) / 1e12 if m_ > 0 else 0):8.1f} TFLOP/s", file=sys.stderr)
+            for k, (m_, f_, c_, b_) in sorted(trace.items(), key=lambda kv: -kv[1][0]):
+                print(f"  {k:20s} {m_ / traced_steps:7.3f} ms/step {100 * m_ / tot:5.1f}%  x{c_ // traced_steps:3d}  "
+                      f"{f_ / (m_ * 1e-3) / 1e12:7.1f} TFLOP/s {b_ / (m_ * 1e-3) / 1e9:7.0f} GB/s", file=sys.stderr)
         base = None
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline()
@@ -211,7 +223,7 @@ def main():
                           "heads": 10, "nb_features": 266, "grad_acc": args.grad_acc,
                           "parallelism": f"dp{world}", "feature_redraw": "disabled",
                           "launch": "eager" if args.eager else "hip-graph replay of the micro-step"},
-               "final_loss": final_loss, "roofline": roof, "cpu_baseline": base}
+               "final_loss": final_loss, "roofline": roof, "cpu_baseline": base, "kernels": kernels}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -133,12 +133,14 @@ int scm_head_bwd(const float* dout, const float* denc, const float* out, const f
  *      launch stream around each launch of the selected kernel.  scm_trace_enable(kid): -1 off,
  *      scm_trace_kernel_count() = every kernel, else one kernel id.  scm_trace_collect waits for the recorded
  *      events and returns, per kernel id, summed milliseconds, summed algorithmic GEMM-term FLOPs
- *      (recomputation not counted) and launch counts, then clears the log.  Arrays are host memory of
+ *      (recomputation not counted), summed algorithmic HBM bytes (each operand read once, each result written
+ *      once) and launch counts, then clears the log.  Arrays are host memory of
  *      scm_trace_kernel_count() entries.  Tracing creates events: keep it off in production loops. */
 int scm_trace_kernel_count(void);
 const char* scm_trace_kernel_name(int kid); /* host */
 int scm_trace_enable(int kid);
-int scm_trace_collect(double* ms /* host */, double* flops /* host */, int64_t* launches /* host */);
+int scm_trace_collect(double* ms /* host */, double* flops /* host */, double* bytes /* host */,
+                      int64_t* launches /* host */);
 
 #ifdef __cplusplus
 }

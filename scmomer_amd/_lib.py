@@ -48,7 +48,8 @@ SIGNATURES = {
     "scm_trace_kernel_count": (i32, []),
     "scm_trace_kernel_name": (C.c_char_p, [i32]),
     "scm_trace_enable": (i32, [i32]),
-    "scm_trace_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "scm_trace_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_int64)]),
     "scm_head_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
     "scm_head_bwd_ws_floats": (i64, [i64, i32, i32]),
     "scm_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

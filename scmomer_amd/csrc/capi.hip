@@ -47,13 +47,13 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_nt", "wgrad", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_kmax", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
     "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix"};
-struct TraceRec { int kid; double flops; hipEvent_t t0, t1; };
+struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
 static bool trace_on(int kid) { return g_trace_kid == K_COUNT || g_trace_kid == kid; }
-void trace_begin(int kid, double flops, hipStream_t s) {
+void trace_begin(int kid, double flops, double bytes, hipStream_t s) {
   if (!trace_on(kid)) return;
-  TraceRec r{kid, flops, nullptr, nullptr};
+  TraceRec r{kid, flops, bytes, nullptr, nullptr};
   if (hipEventCreate(&r.t0) != hipSuccess || hipEventCreate(&r.t1) != hipSuccess) return;
   (void)hipEventRecord(r.t0, s);
   g_trace.push_back(r);
@@ -75,13 +75,13 @@ int scm_trace_enable(int kid) {
   g_trace_kid = kid;
   return 0;
 }
-int scm_trace_collect(double* ms, double* flops, int64_t* launches) {
-  SCM_REQ(ms && flops && launches, "scm_trace_collect: null pointer");
-  for (int i = 0; i < K_COUNT; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+int scm_trace_collect(double* ms, double* flops, double* bytes, int64_t* launches) {
+  SCM_REQ(ms && flops && bytes && launches, "scm_trace_collect: null pointer");
+  for (int i = 0; i < K_COUNT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
   for (auto& r : g_trace) {
     float dt = 0.f;
     if (hipEventSynchronize(r.t1) == hipSuccess && hipEventElapsedTime(&dt, r.t0, r.t1) == hipSuccess) {
-      ms[r.kid] += dt; flops[r.kid] += r.flops; launches[r.kid] += 1;
+      ms[r.kid] += dt; flops[r.kid] += r.flops; bytes[r.kid] += r.bytes; launches[r.kid] += 1;
     }
     (void)hipEventDestroy(r.t0);
     (void)hipEventDestroy(r.t1);
@@ -147,9 +147,8 @@ int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* 
   hipStream_t s = (hipStream_t)stream;
   SCM_HIP(ln_bwd(dy, x, mean, rstd, gamma, dres, T, D, dx, dx_bf16, ws, s), "scm_ln_bwd");
   const int nb = ln_bwd_blocks(T);
-  if (dgamma) SCM_HIP(colsum_reduce(ws, nb, 3 * D, 0, D, dgamma, accumulate, s), "scm_ln_bwd(dgamma)");
-  if (dbeta) SCM_HIP(colsum_reduce(ws, nb, 3 * D, D, 2 * D, dbeta, accumulate, s), "scm_ln_bwd(dbeta)");
-  if (dres_colsum) SCM_HIP(colsum_reduce(ws, nb, 3 * D, 2 * D, 3 * D, dres_colsum, accumulate, s), "scm_ln_bwd(dres)");
+  const ColsumSegs seg{{dgamma, dbeta, dres_colsum, nullptr}, {0, D, 2 * D, 0}, {D, 2 * D, 3 * D, 0}};
+  SCM_HIP(colsum_reduce(ws, nb, 3 * D, seg, 3, accumulate, s), "scm_ln_bwd(column sums)");
   return 0;
 }
 
@@ -307,10 +306,10 @@ int scm_head_bwd(const float* dout, const float* denc, const float* out, const f
   hipStream_t s = (hipStream_t)stream;
   SCM_HIP(head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, W, T, D, C, relu, dx, dx_bf16, ws, s), "scm_head_bwd");
   const int nb = ln_bwd_blocks(T), wd = head_width(D, C);
-  if (dgamma) SCM_HIP(colsum_reduce(ws, nb, wd, 0, D, dgamma, accumulate, s), "scm_head_bwd(dgamma)");
-  if (dbeta) SCM_HIP(colsum_reduce(ws, nb, wd, D, 2 * D, dbeta, accumulate, s), "scm_head_bwd(dbeta)");
-  if (dW && C > 0) SCM_HIP(colsum_reduce(ws, nb, wd, 2 * D, 2 * D + C * D, dW, accumulate, s), "scm_head_bwd(dW)");
-  if (db && C > 0) SCM_HIP(colsum_reduce(ws, nb, wd, 2 * D + C * D, wd, db, accumulate, s), "scm_head_bwd(db)");
+  const ColsumSegs seg{{dgamma, dbeta, C > 0 ? dW : nullptr, C > 0 ? db : nullptr},
+                       {0, D, 2 * D, 2 * D + C * D},
+                       {D, 2 * D, 2 * D + C * D, wd}};
+  SCM_HIP(colsum_reduce(ws, nb, wd, seg, 4, accumulate, s), "scm_head_bwd(column sums)");
   return 0;
 }
 

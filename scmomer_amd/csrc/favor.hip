@@ -775,7 +775,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, int nchunks, float* part,
                       long long* part_key, hipStream_t s) {
   const int chunk_len = round_up((N + nchunks - 1) / nchunks, 32);
-  Traced tr(K_KMAX, 0, s);
+  Traced tr(K_KMAX, 0, s, (double)B * H * N * 128);   // k read once
   hipLaunchKernelGGL(favor_kmax_kernel, dim3(nchunks, B * H), dim3(256), 0, s, k, (const bf16*)omega_b, H, N,
                      chunk_len, part, part_key);
   return hipGetLastError();
@@ -795,7 +795,8 @@ hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
   // algorithmic GEMM-term FLOPs per (token, head): mode 0: scores 2*64*266 + K'^T V 2*266*64;
   // mode 1: q'^T dnum 2*266*64 + dz 2*266 (the recomputed scores are not counted)
   const double th = (double)B * a.H * a.N;
-  Traced tr(mode == 0 ? K_CTX_FWD : K_CTX_BWD, th * (mode == 0 ? 68096.0 : 34580.0), s);
+  // bytes per (token, head): mode 0 reads k, v; mode 1 reads q, dout, the centred output and 3 f32 row scalars
+  Traced tr(mode == 0 ? K_CTX_FWD : K_CTX_BWD, th * (mode == 0 ? 68096.0 : 34580.0), s, th * (mode == 0 ? 256.0 : 396.0));
   if (mode == 0)
     hipLaunchKernelGGL((favor_ctx_kernel<0>), dim3(nchunks, B * a.H), dim3(576), lds, s, a);
   else
@@ -833,7 +834,10 @@ hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s)
   // dS Omega = 68,628; mode 2: v dC^T + k' dC + dS Omega = 102,144 (recomputed scores not counted)
   const double th = (double)B * a.H * a.N;
   Traced tr(mode == 0 ? K_APPLY_FWD : (mode == 1 ? K_APPLY_BWD_Q : K_APPLY_BWD_K),
-            th * (mode == 2 ? 102144.0 : 68628.0), s);
+            th * (mode == 2 ? 102144.0 : 68628.0), s,
+            // bytes per (token, head): mode 0 q in, out + centred out, 2 row scalars; mode 1 q, dout, centred out in,
+            // dq out, 3 row scalars; mode 2 k, v in, dk, dv out
+            th * (mode == 0 ? 392.0 : (mode == 1 ? 524.0 : 512.0)));
   if (mode == 0) hipLaunchKernelGGL((favor_apply_kernel<0>), grid, dim3(512), lds, s, a);
   else if (mode == 1) hipLaunchKernelGGL((favor_apply_kernel<1>), grid, dim3(512), lds, s, a);
   else hipLaunchKernelGGL((favor_apply_kernel<2>), grid, dim3(512), lds, s, a);

@@ -557,6 +557,18 @@ __global__ void cast_weight_kernel(const float* __restrict__ src, int R, int C, 
 // ------------------------------------------------------------------------------------------
 namespace scm {
 
+// algorithmic HBM bytes of one product: A and W read once, every output written once, the epilogue's extra
+// operands (residual, pre-activation) read once
+template <bool A_F32, int EPI>
+static double gemm_bytes(int M, int N, int K, const GemmEpi& e) {
+  const bool f32_out = EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES;
+  double b = (double)M * K * (A_F32 ? 4 : 2) + (double)N * K * 2 + (double)M * N * (f32_out ? 4 : 2);
+  if (EPI == EPI_GELU_DUAL) b += (double)M * N * 2;
+  if (EPI == EPI_DGELU) b += (double)M * N * 2;
+  if (EPI == EPI_F32_BIAS_RES && e.resid) b += (double)M * N * 4;
+  return b;
+}
+
 template <int NT, bool A_F32, int EPI>
 static hipError_t launch_gemm(const void* A, long lda, const bf16* W, long ldw, int M, int N, int K, GemmEpi e,
                               hipStream_t s) {
@@ -564,7 +576,7 @@ static hipError_t launch_gemm(const void* A, long lda, const bf16* W, long ldw, 
   dim3 grid((M + G_BM - 1) / G_BM, (N + BN - 1) / BN);
   size_t lds = (size_t)(G_BM + BN) * 128;
   if (lds < 4 * 32 * G_SP * sizeof(float)) lds = 4 * 32 * G_SP * sizeof(float);
-  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s);
+  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
   hipLaunchKernelGGL((gemm_nt_kernel<NT, A_F32, EPI>), grid, dim3(256), lds, s, A, lda, W, ldw, M, N, K, e);
   return hipGetLastError();
 }
@@ -577,7 +589,7 @@ static hipError_t launch_skinny(const void* A, long lda, const bf16* W, long ldw
   static const int force = getenv("SCM_SK_GRID") ? atoi(getenv("SCM_SK_GRID")) : 0;
   long grid = force > 0 ? force : 768;
   if (grid > total) grid = total;
-  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s);
+  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
   hipLaunchKernelGGL((gemm_skinny_kernel<A_F32, EPI>), dim3((unsigned)grid), dim3(256), SK_WBYTES, s, A, lda, W, ldw,
                      M, N, K, e);
   return hipGetLastError();
@@ -625,7 +637,7 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
   dim3 grid(((P + W_BP - 1) / W_BP) * slices);
   size_t lds = (size_t)W_BT * (W_PP + W_QP);
   const bf16* Pb = (const bf16*)Pm;
-  Traced tr(K_WGRAD, 2.0 * T * P * Q, s);
+  Traced tr(K_WGRAD, 2.0 * T * P * Q, s, (double)T * (P * 2.0 + Q * (q_f32 ? 4.0 : 2.0)) + (double)P * Q * 4);
   if (q_f32 && ones)
     hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(320), lds, s, Pb, ldp, Qm, ldq, T, P, Q, tps, slab);
   else if (q_f32)

@@ -313,14 +313,20 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
-// out[i] (+)= sum_b partial[b][lo + i].  Workgroup = 32 columns x 8 row groups; fixed summation order.
+// Column sums of the per-workgroup partial rows, for up to 4 column segments with their own outputs:
+// seg.out[k][i] (+)= sum_b partial[b][seg.lo[k] + i], i < seg.hi[k] - seg.lo[k].  One launch covers all segments
+// (blockIdx.y = segment).  Workgroup = 32 columns x 8 row groups; fixed summation order.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, int nblocks, int width,
-                                                            int lo, int hi, float* __restrict__ out, int accumulate) {
+                                                            ColsumSegs seg, int accumulate) {
   __shared__ float red[8][33];
+  const int k = blockIdx.y;
+  const int lo = seg.lo[k], n = seg.hi[k] - lo;
+  float* __restrict__ out = seg.out[k];
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + c;
+  if (blockIdx.x * 32 >= n || out == nullptr) return;   // uniform per workgroup
   float s = 0.f;
-  if (i < hi - lo) {
+  if (i < n) {
     const float* p = partial + lo + i;
     int b = rg;
     for (; b + 24 < nblocks; b += 32) {
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   }
   red[rg][c] = s;
   __syncthreads();
-  if (rg == 0 && i < hi - lo) {
+  if (rg == 0 && i < n) {
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) t += red[r][c];
@@ -360,14 +366,14 @@ hipError_t embed_bwd(const int64_t* tok, const float* dx, long T, int D, int V, 
 }
 hipError_t ln_fwd(const float* x, const float* g, const float* b, long T, int D, void* y, float* mean, float* rstd,
                   hipStream_t s) {
-  Traced tr(K_LN_FWD, 0, s);
+  Traced tr(K_LN_FWD, 0, s, (double)T * D * 6);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(row_grid(T)), dim3(256), 0, s, x, g, b, T, D, (bf16*)y, mean, rstd);
   return hipGetLastError();
 }
 int ln_bwd_blocks(long T) { long b = (T + 63) / 64; return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024); }
 hipError_t ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                   const float* dres, long T, int D, float* dx, void* dx_b, float* partial, hipStream_t s) {
-  Traced tr(K_LN_BWD, 0, s);
+  Traced tr(K_LN_BWD, 0, s, (double)T * D * (8 + (dres ? 4 : 0) + 4 + (dx_b ? 2 : 0)));
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_blocks(T)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, T, D, dx,
                      (bf16*)dx_b, partial);
   return hipGetLastError();
@@ -388,13 +394,21 @@ hipError_t head_bwd(const float* dout, const float* denc, const float* out, cons
                      beta, W, T, D, C, relu, dx, (bf16*)dx_b, partial);
   return hipGetLastError();
 }
+hipError_t colsum_reduce(const float* partial, int nblocks, int width, const ColsumSegs& seg, int nseg, int accumulate,
+                         hipStream_t s) {
+  int widest = 0;
+  for (int k = 0; k < nseg; ++k)
+    if (seg.out[k] && seg.hi[k] - seg.lo[k] > widest) widest = seg.hi[k] - seg.lo[k];
+  if (widest == 0) return hipSuccess;
+  Traced tr(K_COLSUM, 0, s);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((widest + 31) / 32, nseg), dim3(256), 0, s, partial, nblocks, width,
+                     seg, accumulate);
+  return hipGetLastError();
+}
 hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, int hi, float* out, int accumulate,
                          hipStream_t s) {
-  const int n = hi - lo;
-  Traced tr(K_COLSUM, 0, s);
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, nblocks, width, lo, hi, out,
-                     accumulate);
-  return hipGetLastError();
+  ColsumSegs seg{{out, nullptr, nullptr, nullptr}, {lo, 0, 0, 0}, {hi, 0, 0, 0}};
+  return colsum_reduce(partial, nblocks, width, seg, 1, accumulate, s);
 }
 
 }  // namespace scm

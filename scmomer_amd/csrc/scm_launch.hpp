@@ -60,11 +60,13 @@ enum KernelId {
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_KMAX, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
   K_APPLY_BWD_K, K_KFIX, K_COUNT
 };
-void trace_begin(int kid, double flops, hipStream_t s);
+void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
 struct Traced {  // brackets one launch
   int kid; hipStream_t s;
-  Traced(int k, double flops, hipStream_t st) : kid(k), s(st) { trace_begin(k, flops, st); }
+  // flops: algorithmic GEMM-term FLOPs of the launch; bytes: its algorithmic HBM bytes (operands read once,
+  // results written once)
+  Traced(int k, double flops, hipStream_t st, double bytes = 0) : kid(k), s(st) { trace_begin(k, flops, bytes, st); }
   ~Traced() { trace_end(kid, s); }
 };
 
@@ -92,6 +94,9 @@ hipError_t head_fwd(const float* x, const float* g, const float* b, const float*
 hipError_t head_bwd(const float* dout, const float* denc, const float* out, const float* x, const float* mean,
                     const float* rstd, const float* gamma, const float* beta, const float* W, long T, int D, int C,
                     int relu, float* dx, void* dx_b, float* partial, hipStream_t s);
+struct ColsumSegs { float* out[4]; int lo[4], hi[4]; };   // column segments [lo,hi) of a partial row -> outputs
+hipError_t colsum_reduce(const float* partial, int nblocks, int width, const ColsumSegs& seg, int nseg, int accumulate,
+                         hipStream_t s);
 hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, int hi, float* out, int accumulate,
                          hipStream_t s);
 

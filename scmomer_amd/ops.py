@@ -50,20 +50,25 @@ def view4(t: torch.Tensor) -> View4:
 
 
 # ----------------------------------------------------------------------------- parameters
-def cast_weight(w: torch.Tensor, want_plain=True, want_t=True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+def cast_weight(w: torch.Tensor, want_plain=True, want_t=True, out=None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """f32 [r,c] -> (bf16 [r,c], bf16 [c,r]); `out` = an earlier result pair to overwrite in place"""
     _req(w, F32, "weight")
     r, c = w.shape
-    wb = torch.empty((r, c), dtype=BF16, device=w.device) if want_plain else None
-    wt = torch.empty((c, r), dtype=BF16, device=w.device) if want_t else None
+    if out is not None:
+        wb, wt = out
+    else:
+        wb = torch.empty((r, c), dtype=BF16, device=w.device) if want_plain else None
+        wt = torch.empty((c, r), dtype=BF16, device=w.device) if want_t else None
     check(lib.scm_cast_weight(_p(w), r, c, _p(wb), _p(wt), _stream()), "scm_cast_weight")
     return wb, wt
 
 
-def prep_omega(omega: torch.Tensor) -> torch.Tensor:
+def prep_omega(omega: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(omega, F32, "projection_matrix")
     if tuple(omega.shape) != (NB_FEATURES, DIM_HEAD):
         raise ValueError(f"projection_matrix must be [266,64], got {tuple(omega.shape)}")
-    out = torch.empty((NB_FEATURES_PAD, DIM_HEAD), dtype=BF16, device=omega.device)
+    if out is None:
+        out = torch.empty((NB_FEATURES_PAD, DIM_HEAD), dtype=BF16, device=omega.device)
     check(lib.scm_prep_omega(_p(omega), _p(out), _stream()), "scm_prep_omega")
     return out
 
@@ -247,9 +252,10 @@ def trace_enable(which):
 
 
 def trace_collect():
-    """-> {name: (milliseconds, algorithmic_flops, launches)} for kernels with launches; clears the log."""
+    """-> {name: (milliseconds, algorithmic_flops, launches, algorithmic_bytes)} for kernels with launches;
+    clears the log."""
     n = lib.scm_trace_kernel_count()
-    ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
-    check(lib.scm_trace_collect(ms, fl, cnt), "scm_trace_collect")
+    ms, fl, by, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+    check(lib.scm_trace_collect(ms, fl, by, cnt), "scm_trace_collect")
     names = trace_kernel_names()
-    return {names[i]: (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
+    return {names[i]: (ms[i], fl[i], cnt[i], by[i]) for i in range(n) if cnt[i] > 0}

@@ -50,52 +50,69 @@ def _ver(*ts) -> tuple:
 
 
 class WeightCache:
-    """bf16 (and transposed bf16) copies of the f32 master weights, refreshed when a parameter's
-    storage or version counter changes (optimizer steps and load_state_dict bump the version)."""
-
-    enabled = True   # set False when forward is captured into a graph: the casts must replay with it
+    """bf16 (and transposed bf16) copies of the f32 master weights, refreshed when a parameter's storage or
+    version counter changes (optimizer steps and load_state_dict bump the version).  A refresh rewrites the
+    SAME device buffers, so a HIP graph captured over forward/backward keeps reading valid copies: while a
+    stream is capturing, existing copies are used as they are (no cast is recorded into the graph), and the
+    owner refreshes them eagerly after each weight update (refresh_weights)."""
 
     def __init__(self):
         self.store: Dict[Any, Tuple[tuple, dict]] = {}
 
+    def _lookup(self, key, ver):
+        hit = self.store.get(key)
+        if hit is not None and (hit[0] == ver or torch.cuda.is_current_stream_capturing()):
+            return hit, True
+        if hit is not None and hit[1].get("device") != ver[0]:
+            hit = None                      # moved to another device: new buffers
+        return hit, False
+
     def attn(self, key, p) -> dict:
-        ver = _ver(p["wq"], p["wk"], p["wv"], p["wo"], p["omega"], p["bq"], p["bk"], p["bv"])
-        hit = self.store.get(("a", key))
-        if torch.cuda.is_current_stream_capturing():
-            # casts made while capturing belong to that graph and are replayed with it
-            if hit is not None and hit[0] == ("captured",):
-                return hit[1]
-            ver = ("captured",)
-        elif hit is not None and hit[0] == ver and WeightCache.enabled:
+        ver = (p["wq"].device,) + _ver(p["wq"], p["wk"], p["wv"], p["wo"], p["omega"], p["bq"], p["bk"], p["bv"])
+        hit, fresh = self._lookup(("a", key), ver)
+        if fresh:
             return hit[1]
+        old = hit[1] if hit is not None else None
         with torch.no_grad():
             wqkv = torch.cat([p["wq"], p["wk"], p["wv"]], 0).to(F32).contiguous()
-            wqkv_b, wqkv_t = ops.cast_weight(wqkv)
-            wo_b, wo_t = ops.cast_weight(p["wo"].detach().to(F32).contiguous())
-            omega_b = ops.prep_omega(p["omega"].detach().to(F32).contiguous())
+            wqkv_b, wqkv_t = ops.cast_weight(wqkv, out=(old["wqkv"], old["wqkv_t"]) if old else None)
+            wo_b, wo_t = ops.cast_weight(p["wo"].detach().to(F32).contiguous(),
+                                         out=(old["wo"], old["wo_t"]) if old else None)
+            omega_b = ops.prep_omega(p["omega"].detach().to(F32).contiguous(), out=old["omega_b"] if old else None)
             bqkv = None
             if p["bq"] is not None:
                 bqkv = torch.cat([p["bq"], p["bk"], p["bv"]], 0).to(F32).contiguous()
-        out = {"wqkv": wqkv_b, "wqkv_t": wqkv_t, "wo": wo_b, "wo_t": wo_t, "omega_b": omega_b, "bqkv": bqkv}
+                if old is not None and old["bqkv"] is not None:
+                    bqkv = old["bqkv"].copy_(bqkv)
+        out = {"wqkv": wqkv_b, "wqkv_t": wqkv_t, "wo": wo_b, "wo_t": wo_t, "omega_b": omega_b, "bqkv": bqkv,
+               "device": ver[0]}
         self.store[("a", key)] = (ver, out)
         return out
 
     def ffn(self, key, p) -> dict:
-        ver = _ver(p["w1"], p["w2"])
-        hit = self.store.get(("f", key))
-        if torch.cuda.is_current_stream_capturing():
-            # casts made while capturing belong to that graph and are replayed with it
-            if hit is not None and hit[0] == ("captured",):
-                return hit[1]
-            ver = ("captured",)
-        elif hit is not None and hit[0] == ver and WeightCache.enabled:
+        ver = (p["w1"].device,) + _ver(p["w1"], p["w2"])
+        hit, fresh = self._lookup(("f", key), ver)
+        if fresh:
             return hit[1]
+        old = hit[1] if hit is not None else None
         with torch.no_grad():
-            w1_b, w1_t = ops.cast_weight(p["w1"].detach().to(F32).contiguous())
-            w2_b, w2_t = ops.cast_weight(p["w2"].detach().to(F32).contiguous())
-        out = {"w1": w1_b, "w1_t": w1_t, "w2": w2_b, "w2_t": w2_t}
+            w1_b, w1_t = ops.cast_weight(p["w1"].detach().to(F32).contiguous(),
+                                         out=(old["w1"], old["w1_t"]) if old else None)
+            w2_b, w2_t = ops.cast_weight(p["w2"].detach().to(F32).contiguous(),
+                                         out=(old["w2"], old["w2_t"]) if old else None)
+        out = {"w1": w1_b, "w1_t": w1_t, "w2": w2_b, "w2_t": w2_t, "device": ver[0]}
         self.store[("f", key)] = (ver, out)
         return out
+
+
+def refresh_weights(owner) -> None:
+    """Bring the bf16 weight copies of a PerformerLM / Performer up to date now (in place).  Needed only by callers
+    that replay a captured graph of the step: call it after every weight update, outside the graph."""
+    performer = getattr(owner, "performer", owner)
+    cache = _cache_of(owner)
+    for li, (f, g) in enumerate(performer.net.layers):
+        cache.attn(li, attn_params(f))
+        cache.ffn(li, ffn_params(g))
 
 
 def _cache_of(owner) -> WeightCache:

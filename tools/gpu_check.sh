@@ -7,4 +7,4 @@ rc=$?; echo "tests exit $rc"; tail -3 gpurun_out/t_$TAG.log
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 --trace-all --no-cpu-baseline > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 echo "bench exit $?"
 python -c "import json;d=json.load(open('gpurun_out/bench_$TAG.json'));print('cells/s',round(d['value'],1),'ms/step',round(d['ms_per_step'],3),'loss',d['final_loss'])"
-grep -v -E "amdgpu.ids|Warn|run_backward" gpurun_out/bench_$TAG.err | head -${3:-18}
+grep -v -E "amdgpu.ids|Warn|run_backward" gpurun_out/bench_$TAG.err | head -${3:-20}
