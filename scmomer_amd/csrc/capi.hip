@@ -44,7 +44,9 @@ static TensorBHND_out oview(const scm_view4& v) { return {(bf16*)v.p, (long)v.sb
 // ---------------------------------------------------------------------------- per-kernel event tracing
 namespace scm {
 static const char* const kKernelNames[K_COUNT] = {
-    "gemm_nt", "wgrad", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
+    "gemm_nt/bf16", "gemm_nt/f32_bias_res", "gemm_nt/gelu_dual", "gemm_nt/dgelu", "gemm_nt/f32", "gemm_nt/bf16_bias",
+    "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
+    "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_kmax", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
     "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };

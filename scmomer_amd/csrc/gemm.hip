@@ -514,6 +514,131 @@ __global__ __launch_bounds__(320) void wgrad_kernel(const bf16* __restrict__ Pm,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad_dma: the same product for bf16 operands, fed by asynchronous global->LDS copies.
+//   workgroup = 4 waves (one per SIMD), 128 P columns x up to 224 Q columns, 64-token stages in a ring of 3:
+//   while stage i is multiplied, the copies of stages i+1 and i+2 are in flight (no staging registers, one
+//   barrier per stage).  P stage: [64][128] bf16, 256-byte rows, 64-byte units XOR-swizzled by (row & 3) so that
+//   the transposing reads are conflict free; Q stage: [64][224] bf16 at a 448-byte pitch.
+// ------------------------------------------------------------------------------------------
+constexpr int WD_BP = 128;
+constexpr int WD_PBYTES = W_BT * 256;             // 16 KB
+constexpr int WD_QBYTES = W_BT * W_QP;            // 28 KB
+constexpr int WD_STAGE = WD_PBYTES + WD_QBYTES;   // 44 KB
+constexpr int WD_NSTAGE = 3;
+
+template <bool ONES>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__ Pm, long ldp,
+                                                        const bf16* __restrict__ Qm, long ldq, int T, int P, int Q,
+                                                        int tiles_per_slice, float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  const int ptiles = (P + WD_BP - 1) / WD_BP;
+  int slice, ptile;
+  {  // blocks b and b+8 share an XCD: the P tiles of one token slice run on one XCD and share the Q stage in its L2
+    const int b = blockIdx.x, nslices = gridDim.x / ptiles, full = (nslices / 8) * 8 * ptiles;
+    if (b < full) { slice = (b % 8) + 8 * (b / (8 * ptiles)); ptile = (b / 8) % ptiles; }
+    else { slice = (nslices / 8) * 8 + (b - full) / ptiles; ptile = (b - full) % ptiles; }
+  }
+  const int p0 = ptile * WD_BP;
+  const int ntiles = (T + W_BT - 1) / W_BT;
+  const int tile_lo = slice * tiles_per_slice;
+  const int tile_hi = min(ntiles, tile_lo + tiles_per_slice);
+  const int qchunks = Q >> 3;
+  const u32x4 rP = dma_rsrc(Pm, (uint32_t)(((long)(T - 1) * ldp + P) * 2));
+  const u32x4 rQ = dma_rsrc(Qm, (uint32_t)(((long)(T - 1) * ldq + Q) * 2));
+  const int wu = __builtin_amdgcn_readfirstlane(w);   // wave index as a scalar (LDS copy bases live in M0)
+  const uint32_t lds0 = lds_addr_of(smem);
+
+  // per-lane source offsets of this wave's copies (relative to the stage's first token)
+  uint32_t pv[4], qv[7];
+  bool qmask[7];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {        // P: copy j = 4 w + jj fills rows 4j .. 4j+3 (1 KB)
+    const int row = 4 * (4 * w + jj) + (l >> 4);
+    const int chunk = (l & 15) ^ ((row & 3) << 2);
+    pv[jj] = (p0 + 8 * chunk < P) ? (uint32_t)(row * ldp + p0 + 8 * chunk) * 2 : BUF_OOB;
+  }
+#pragma unroll
+  for (int jj = 0; jj < 7; ++jj) {        // Q: copy j = 7 w + jj fills bytes [1024 j, 1024 j + 1024) of the stage
+    const int off = 1024 * (7 * w + jj) + 16 * l;
+    const int row = off / W_QP, chunk = (off - row * W_QP) >> 4;
+    qv[jj] = chunk < qchunks ? (uint32_t)(row * ldq + 8 * chunk) * 2 : BUF_OOB;   // padding chunks receive zeros
+    qmask[jj] = !(ONES && chunk == qchunks);                                       // the ones column is kept
+  }
+  auto issue = [&](int tile, int buf) {
+    const uint32_t pb = lds0 + buf * WD_STAGE, qb = pb + WD_PBYTES;
+    const bool live = tile < tile_hi;     // past the slice: nothing is copied (the stage is not read either)
+    const uint32_t sp = (uint32_t)((long)tile * W_BT * ldp * 2), sq = (uint32_t)((long)tile * W_BT * ldq * 2);
+    if (live) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) dma16_to_lds(rP, pb + 1024 * (4 * wu + jj), pv[jj], sp);
+#pragma unroll
+      for (int jj = 0; jj < 7; ++jj) {
+        if (!ONES || qmask[jj]) dma16_to_lds(rQ, qb + 1024 * (7 * wu + jj), qv[jj], sq);
+      }
+    }
+  };
+  if (ONES) {   // column Q of every stage = 1 (tokens past T multiply zero-filled P rows)
+    for (int i = tid; i < WD_NSTAGE * W_BT; i += 256) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+      o[0] = (bf16)1.f;
+      *(bf16x8*)(smem + (i / W_BT) * WD_STAGE + WD_PBYTES + (i % W_BT) * W_QP + qchunks * 16) = o;
+    }
+  }
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = zero16();
+
+  // fragment addresses: k runs over stage rows (tokens), read with the transposing LDS read
+  const int g = l >> 4, i16 = l & 15;
+  const int frow = 8 * (g >> 1) + (i16 >> 2);                 // + 16 s (+4 for the upper half of the fragment)
+  const int acol = 32 * w + 16 * (g & 1) + 4 * (i16 & 3);     // P column of this lane's 4-element group
+  const int a_off = frow * 256 + ((((acol >> 3) ^ ((frow & 3) << 2))) << 4) + (acol & 7) * 2;
+  const int b_off = frow * W_QP + (16 * (g & 1) + 4 * (i16 & 3)) * 2;
+
+  issue(tile_lo, 0);
+  issue(tile_lo + 1, 1);
+  int buf = 0;
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    // this wave's copies of `tile` have landed once at most one later stage (11 copies) is still in flight
+    if (tile + 1 < tile_hi) wait_vmcnt<11>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();          // everyone's copies landed; everyone is done reading stage tile-1
+    issue(tile + 2, buf == 0 ? 2 : buf - 1);
+    const char* pb = smem + buf * WD_STAGE;
+    const char* qb = pb + WD_PBYTES;
+#pragma unroll
+    for (int s = 0; s < W_BT / 16; ++s) {
+      const bf16x4 alo = lds_tr_read(pb + a_off + s * 4096), ahi = lds_tr_read(pb + a_off + s * 4096 + 1024);
+      const bf16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const bf16x4 blo = lds_tr_read(qb + b_off + s * (16 * W_QP) + t * 64);
+        const bf16x4 bhi = lds_tr_read(qb + b_off + s * (16 * W_QP) + t * 64 + 4 * W_QP);
+        const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        acc[t] = mfma32(a, b, acc[t]);
+      }
+    }
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+
+  float* out = slab + (long)slice * P * W_LDSLAB;
+  const int qlim = ONES ? Q + 1 : Q;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int col = 32 * t + (l & 31);
+    if (col >= qlim) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = p0 + 32 * w + acc_row(r, half);
+      if (p < P) out[(long)p * W_LDSLAB + col] = acc[t][r];
+    }
+  }
+}
+
 // grad (+)= sum_s slab[s][p][q];  trans: grad is [Q,P] (grad[q*P+p]) else [P,Q].
 // bias (+)= sum_s slab[s][p][Q]  when bias != null.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int S, int P, int Q, float* __restrict__ grad,
@@ -576,7 +701,7 @@ static hipError_t launch_gemm(const void* A, long lda, const bf16* W, long ldw, 
   dim3 grid((M + G_BM - 1) / G_BM, (N + BN - 1) / BN);
   size_t lds = (size_t)(G_BM + BN) * 128;
   if (lds < 4 * 32 * G_SP * sizeof(float)) lds = 4 * 32 * G_SP * sizeof(float);
-  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
+  Traced tr(K_GEMM_NT + EPI, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
   hipLaunchKernelGGL((gemm_nt_kernel<NT, A_F32, EPI>), grid, dim3(256), lds, s, A, lda, W, ldw, M, N, K, e);
   return hipGetLastError();
 }
@@ -589,7 +714,7 @@ static hipError_t launch_skinny(const void* A, long lda, const bf16* W, long ldw
   static const int force = getenv("SCM_SK_GRID") ? atoi(getenv("SCM_SK_GRID")) : 0;
   long grid = force > 0 ? force : 768;
   if (grid > total) grid = total;
-  Traced tr(K_GEMM_NT, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
+  Traced tr(K_GEMM_SKINNY + EPI, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
   hipLaunchKernelGGL((gemm_skinny_kernel<A_F32, EPI>), dim3((unsigned)grid), dim3(256), SK_WBYTES, s, A, lda, W, ldw,
                      M, N, K, e);
   return hipGetLastError();
@@ -634,10 +759,27 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
                  int slices, float* slab, hipStream_t s) {
   const int ntiles = (T + W_BT - 1) / W_BT;
   const int tps = (ntiles + slices - 1) / slices;
+  const bf16* Pb = (const bf16*)Pm;
+  Traced tr(ones ? K_WGRAD_BIAS : K_WGRAD, 2.0 * T * P * Q, s, (double)T * (P * 2.0 + Q * (q_f32 ? 4.0 : 2.0)) + (double)P * Q * 4);
+  const long lim = 1l << 31;
+  if (!q_f32 && (long)T * ldp * 2 < lim && (long)T * ldq * 2 < lim) {
+    // bf16 operands: asynchronous global->LDS pipeline
+    const size_t lds = (size_t)WD_NSTAGE * WD_STAGE;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    dim3 grid(((P + WD_BP - 1) / WD_BP) * slices);
+    if (ones)
+      hipLaunchKernelGGL((wgrad_dma_kernel<true>), grid, dim3(256), lds, s, Pb, ldp, (const bf16*)Qm, ldq, T, P, Q, tps, slab);
+    else
+      hipLaunchKernelGGL((wgrad_dma_kernel<false>), grid, dim3(256), lds, s, Pb, ldp, (const bf16*)Qm, ldq, T, P, Q, tps, slab);
+    return hipGetLastError();
+  }
   dim3 grid(((P + W_BP - 1) / W_BP) * slices);
   size_t lds = (size_t)W_BT * (W_PP + W_QP);
-  const bf16* Pb = (const bf16*)Pm;
-  Traced tr(K_WGRAD, 2.0 * T * P * Q, s, (double)T * (P * 2.0 + Q * (q_f32 ? 4.0 : 2.0)) + (double)P * Q * 4);
   if (q_f32 && ones)
     hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(320), lds, s, Pb, ldp, Qm, ldq, T, P, Q, tps, slab);
   else if (q_f32)

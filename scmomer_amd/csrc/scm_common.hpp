@@ -135,6 +135,28 @@ SCM_DEV bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 SCM_DEV f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
 SCM_DEV u32x4 as_u32x4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
 
+// Asynchronous global -> LDS copy of 16 bytes per lane (buffer_load_dwordx4 ... lds): lane i's bytes land at
+// LDS byte address lds_wave_base + 16 i (wave-uniform base, placed in M0), no VGPR staging; lanes whose offset is
+// out of the resource's range write zeros.  Written as inline assembly on purpose: the compiler then neither
+// counts these copies nor orders LDS reads against them, so several stages can stay in flight; the consumer
+// waits with wait_vmcnt<N>() (copies complete in issue order) and then synchronises the workgroup.
+SCM_DEV u32x4 dma_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+SCM_DEV uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+SCM_DEV void dma16_to_lds(u32x4 rsrc, uint32_t lds_wave_base, uint32_t voffset, uint32_t soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_wave_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+// s_waitcnt vmcnt(N) only (expcnt/lgkmcnt left alone): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4]<<14
+template <int N>
+SCM_DEV void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 rounding level): one rcp, one exp2, five fma.
 // libm's erff costs ~50 VALU instructions per element, which made the GELU epilogues VALU-bound.
 // Returns erf(|x|/sqrt2) pieces shared by gelu and its derivative: phi = exp(-x^2/2).

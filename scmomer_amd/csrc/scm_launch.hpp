@@ -55,8 +55,10 @@ struct ApplyArgs {
 constexpr int W_LDSLAB = 208;   // floats per wgrad slab row
 
 // Optional per-kernel timing with HIP events on the launch stream (scm_trace_* in the C ABI).
-enum KernelId {
-  K_GEMM_NT = 0, K_WGRAD, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
+enum KernelId {   // one id per kernel symbol family that a profiler lists separately
+  K_GEMM_NT = 0,            // gemm_nt_kernel, + epilogue id (6 consecutive ids)
+  K_GEMM_SKINNY = 6,        // gemm_skinny_kernel, + epilogue id (6 consecutive ids)
+  K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_KMAX, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
   K_APPLY_BWD_K, K_KFIX, K_COUNT
 };

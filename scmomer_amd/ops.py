@@ -49,6 +49,15 @@ def view4(t: torch.Tensor) -> View4:
     return View4(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
 
 
+def empty_rows(t: int, n: int, dtype, device) -> torch.Tensor:
+    """[t, n] tensor whose row pitch is a multiple of 128 bytes (a view of a wider buffer when n is not): the
+    64-column output chunks of the skinny GEMM then cover whole 128-byte lines, which avoids partial-line writes."""
+    per = 128 // torch.empty((), dtype=dtype).element_size()
+    ld = (n + per - 1) // per * per
+    buf = torch.empty((t, ld), dtype=dtype, device=device)
+    return buf if ld == n else buf[:, :n]
+
+
 # ----------------------------------------------------------------------------- parameters
 def cast_weight(w: torch.Tensor, want_plain=True, want_t=True, out=None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """f32 [r,c] -> (bf16 [r,c], bf16 [c,r]); `out` = an earlier result pair to overwrite in place"""
@@ -137,11 +146,12 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, *, out0: torch.Tensor, o
     return out0
 
 
-def wgrad_slices(t: int, p: int) -> int:
-    """token slices so that ceil(P/160) * slices workgroups are about one per CU (256); every slice costs a
-    [P,208] f32 slab of extra traffic, so no more than that"""
+def wgrad_slices(t: int, p: int, q_bf16: bool = True) -> int:
+    """token slices so that P-tiles * slices workgroups are about one per CU (256); every slice costs a
+    [P,208] f32 slab of extra traffic, so no more than that.  P tiles are 128 wide for bf16 operands (the
+    asynchronous-copy kernel) and 160 wide when the Q operand is f32."""
     tiles = max(1, (t + 63) // 64)
-    ptiles = (p + 159) // 160
+    ptiles = (p + 127) // 128 if q_bf16 else (p + 159) // 160
     return max(1, min(tiles, 256 // ptiles))
 
 
@@ -149,7 +159,7 @@ def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, tra
     """grad (+)= pm^T qm  ([P,Q], or its transpose when trans); bias_grad (+)= column sums of pm."""
     t, p = pm.shape
     q = qm.shape[1]
-    s = wgrad_slices(t, p)
+    s = wgrad_slices(t, p, qm.dtype == BF16)
     ws = torch.empty(lib.scm_wgrad_ws_floats(p, s), dtype=F32, device=pm.device)
     check(lib.scm_wgrad(_p(pm), pm.stride(0), _p(qm), qm.stride(0), int(qm.dtype == F32), t, p, q, s, _p(ws),
                         _p(grad), _p(bias_grad), int(trans), int(accumulate), _stream()), "scm_wgrad")

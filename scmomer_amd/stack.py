@@ -240,8 +240,8 @@ def ffn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torc
         h, mean, rstd = ops.ln_fwd(x2, p["g2"], p["b2"])
     else:
         h, mean, rstd = x2.to(BF16), None, None
-    pre = torch.empty((t, f), dtype=BF16, device=x.device)
-    act = torch.empty((t, f), dtype=BF16, device=x.device)
+    pre = ops.empty_rows(t, f, BF16, x.device)
+    act = ops.empty_rows(t, f, BF16, x.device)
     ops.gemm_nt(ops.EPI_GELU_DUAL, h, w["w1"], out0=pre, out1=act, bias=p["c1"])
     y = torch.empty((t, d), dtype=F32, device=x.device)
     ops.gemm_nt(ops.EPI_F32_BIAS_RES, act, w["w2"], out0=y, bias=p["c2"],
@@ -263,7 +263,7 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
         ops.wgrad(tp.act, dy if dy_b is None else dy_b, g["w2"], None, True, False)
     need_dh = need_dx or (ln and (need["g2"] or need["b2"]))
     if need["w1"] or need["c1"] or need_dh:
-        dpre = torch.empty((t, f), dtype=BF16, device=dev)
+        dpre = ops.empty_rows(t, f, BF16, dev)
         ops.gemm_nt(ops.EPI_DGELU, dy if dy_b is None else dy_b, w["w2_t"], out0=dpre, pre=tp.pre)
         if need["w1"] or need["c1"]:
             g["w1"] = torch.empty((f, d), dtype=F32, device=dev)

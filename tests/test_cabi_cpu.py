@@ -51,7 +51,7 @@ def test_version_and_host_only_calls():
     assert lib.scm_ln_bwd_ws_floats(50718, 200) > 0
     n = lib.scm_trace_kernel_count()
     names = [lib.scm_trace_kernel_name(i).decode() for i in range(n)]
-    assert "favor_apply_fwd" in names and "gemm_nt" in names and len(set(names)) == n
+    assert "favor_apply_fwd" in names and "gemm_skinny/bf16" in names and len(set(names)) == n
 
 
 def test_bad_arguments_are_rejected_without_a_launch():

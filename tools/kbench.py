@@ -42,8 +42,8 @@ def wgrad_case(name, P, qdtype, trans, bias):
     cases.append((name, lambda: ops.wgrad(pm, qm, g, b, trans, False), 2.0 * T * P * 200, T * P * 2 + T * 200 * qm.element_size()))
 wgrad_case("wgrad P1920 bf16", 1920, bf, False, False)
 wgrad_case("wgrad P800 bf16 +bias", 800, bf, False, True)
-wgrad_case("wgrad P800 f32 trans", 800, f32, True, False)
-wgrad_case("wgrad P640 f32 trans", 640, f32, True, False)
+wgrad_case("wgrad P800 bf16 trans", 800, bf, True, False)
+wgrad_case("wgrad P640 bf16 trans", 640, bf, True, False)
 filt = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, fn, flops, by in cases:
     if filt and filt not in name: continue
