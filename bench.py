@@ -102,8 +102,10 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4)
     loss_fn = torch.nn.CrossEntropyLoss(ignore_index=6, reduction="mean")
-    for p in params:                       # static gradient buffers: micro-steps accumulate into them
-        p.grad = torch.zeros_like(p)
+    # Gradient accumulation over the grad_acc micro-steps: backward hands each parameter a fresh gradient
+    # (p.grad is None, so autograd stores it without an add kernel) and ONE multi-tensor add folds all of them into
+    # static accumulators; the accumulators become p.grad for the all-reduce / clip / Adam of the sync step.
+    accs = [torch.zeros_like(p) for p in params]
     averager = sdist.GradientAverager(params)   # one flat bucket, one all-reduce per optimizer step
 
     # each rank owns its own shard of synthetic cells (resident in HBM before timing starts)
@@ -117,15 +119,22 @@ def main():
         masked, labels = s1.data_mask(static_tok, 0.15, 0.9, 6, 6)
         loss = loss_fn(model(masked).transpose(1, 2), labels) / args.grad_acc
         loss.backward()
+        torch._foreach_add_(accs, [p.grad for p in params])
+        for p in params:
+            p.grad = None
         static_loss.copy_(loss.detach())
 
     def sync_step():
         """every grad_acc micro-steps: average gradients over ranks (what DDP's reducer does on the sync
         step, s1_pretrain_rna.py:299-305), clip, Adam, zero"""
+        for p, a in zip(params, accs):
+            p.grad = a
         averager.average_()
         torch.nn.utils.clip_grad_norm_(params, int(1e2))
         opt.step()
-        opt.zero_grad(set_to_none=False)
+        torch._foreach_zero_(accs)
+        for p in params:
+            p.grad = None
         stack.refresh_weights(model)       # bf16 operand copies of the updated weights (in place, outside the graph)
 
     # The micro-step is launch-bound when driven from Python (about 250 kernel launches), so it is captured
@@ -142,7 +151,7 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             micro_step()
-        opt.zero_grad(set_to_none=False)
+        torch._foreach_zero_(accs)         # warm-up and capture passes do not count
 
     def step(i):
         static_tok.copy_(data[i % n_batches])

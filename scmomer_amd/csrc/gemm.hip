@@ -205,6 +205,87 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const void* __restrict__ A
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_nt_dma: Y[M, N<=224] = A[M,K] * W[N,K]^T for bf16 A, fed by asynchronous global->LDS copies.
+//   The rows are dealt out EVENLY: workgroup b owns rows [M b/G, M (b+1)/G), at most 224 of them (7 waves x 32
+//   rows x 7 accumulators), with G a multiple of the CU count, so one round of workgroups keeps every CU equally
+//   busy on this bandwidth-bound product.  64-wide k stages alternate between two LDS buffers: while stage i is
+//   multiplied, the copies of stage i+1 are in flight (no staging registers, one barrier per stage).  The LDS
+//   images are the swizzled 128-byte-row images of gemm_nt (each lane of a copy fetches the 16-byte chunk that
+//   belongs at its linear LDS position).  Epilogue: the LDS-staged coalesced one above.
+// ------------------------------------------------------------------------------------------
+constexpr int GD_NT = 7;                       // accumulator tiles per wave (N <= 224)
+constexpr int GD_ROWS = 224;                   // rows per workgroup (7 waves)
+constexpr int GD_STAGE = (GD_ROWS + GD_NT * 32) * 128;   // 56 KB
+
+template <int EPI>
+__global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict__ A, long lda,
+                                                          const bf16* __restrict__ W, long ldw, int M, int N, int K,
+                                                          GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const long r0 = (long)M * blockIdx.x / gridDim.x, r1 = (long)M * (blockIdx.x + 1) / gridDim.x;
+  const int nk = (K + G_BK - 1) / G_BK;
+  const u32x4 rA = dma_rsrc(A, (uint32_t)(((long)(M - 1) * lda + K) * 2));
+  const u32x4 rW = dma_rsrc(W, (uint32_t)(((long)(N - 1) * ldw + K) * 2));
+  const uint32_t lds0 = lds_addr_of(smem);
+
+  // per-lane source offsets (k-tile 0); a copy covers 8 image rows: lane -> row 8j + (l>>3), linear chunk l&7,
+  // which holds source chunk (l&7) ^ swizzle(row)
+  uint32_t av[4], wv[4];
+  int kc[4];                // source chunk index of this lane (the same for the A and the W copies)
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int row = 8 * (4 * w + jj) + (l >> 3);
+    const int c = swz128(row, l & 7);
+    kc[jj] = c;
+    av[jj] = (r0 + row < r1) ? (uint32_t)((r0 + row) * lda + 8 * c) * 2 : BUF_OOB;
+    wv[jj] = (row < N) ? (uint32_t)((long)row * ldw + 8 * c) * 2 : BUF_OOB;
+  }
+  auto issue = [&](int kt, int buf) {
+    if (kt >= nk) return;
+    const uint32_t ab = lds0 + buf * GD_STAGE, wb = ab + GD_ROWS * 128;
+    const uint32_t so = (uint32_t)kt * (G_BK * 2);
+    const int kleft = (K - kt * G_BK) >> 3;     // valid 16-byte chunks of this k-tile (>= 8 except in the tail)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const bool ok = kc[jj] < kleft;
+      dma16_to_lds(rA, ab + 1024 * (4 * wu + jj), ok ? av[jj] : BUF_OOB, so);
+      dma16_to_lds(rW, wb + 1024 * (4 * wu + jj), ok ? wv[jj] : BUF_OOB, so);
+    }
+  };
+
+  f32x16 acc[GD_NT];
+#pragma unroll
+  for (int t = 0; t < GD_NT; ++t) acc[t] = zero16();
+  int roff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) roff[i] = img_off(l & 31, 16 * i + 8 * (l >> 5));
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();                       // this wave's copies of stage kt have landed
+    __builtin_amdgcn_s_barrier();          // everyone's have; everyone is done reading the other buffer
+    issue(kt + 1, (kt + 1) & 1);
+    const char* Aw = smem + (kt & 1) * GD_STAGE + 4096 * w;
+    const char* Ws = smem + (kt & 1) * GD_STAGE + GD_ROWS * 128;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const bf16x8 a = *(const bf16x8*)(Aw + roff[s2]);
+#pragma unroll
+      for (int t = 0; t < GD_NT; ++t) acc[t] = mfma32(a, *(const bf16x8*)(Ws + 4096 * t + roff[s2]), acc[t]);
+    }
+  }
+  __syncthreads();                          // all reads of the buffers are done: reuse them as the epilogue stage
+  float* stage = (float*)smem + w * (32 * G_SP);
+  const int mlim = (int)r1;                 // rows from r1 on belong to the next workgroup
+#pragma unroll
+  for (int tp = 0; tp < (GD_NT + 1) / 2; ++tp)
+    epilogue_pair<EPI>(stage, acc[2 * tp], acc[(2 * tp + 1 < GD_NT) ? 2 * tp + 1 : 2 * tp], 2 * tp + 1 < GD_NT,
+                       r0 + 32 * w, 64 * tp, mlim, N, e);
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_skinny: Y[M,N] = A[M,K] * W[N,K]^T for K in (192, 208] (the model dim).
 //  * the A fragments of a wave's 32 rows (13 k-steps) are loaded from global memory straight into
 //    REGISTERS once and stay there; the workgroup walks its range of output columns 64 at a time,
@@ -731,6 +812,21 @@ static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, 
   if (fits && K > 16 * (SK_KS - 1) && K <= 16 * SK_KS && N >= 256 &&
       (EPI == EPI_BF16 || EPI == EPI_BF16_BIAS || EPI == EPI_GELU_DUAL || EPI == EPI_DGELU))
     return launch_skinny<A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
+  if (!A_F32 && N <= 224 && K >= 128 && (long)M * lda * 2 < lim && (long)N * ldw * 2 < lim) {
+    const size_t lds = (size_t)2 * GD_STAGE;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    // whole rounds of 256 workgroups with at most 224 rows each; small problems: one workgroup per 32 rows
+    long grid = 256 * (((long)M + 256l * GD_ROWS - 1) / (256l * GD_ROWS));
+    if (grid > (M + 31) / 32) grid = (M + 31) / 32;
+    Traced tr(K_GEMM_NT + EPI, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI>), dim3((unsigned)grid), dim3(448), lds, s, (const bf16*)A, lda, W,
+                       ldw, M, N, K, e);
+    return hipGetLastError();
+  }
   if (N <= 224) return launch_gemm<7, A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
   if (N % 160 == 0) return launch_gemm<5, A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
   return launch_gemm<4, A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
