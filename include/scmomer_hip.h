@@ -89,7 +89,7 @@ int scm_wgrad(const void* Pm_bf16, int64_t ldp, const void* Qm, int64_t ldq, int
  *      softmax_kernel (:67-92, query and key modes) + linear_attention (:144-149) --------------- */
 typedef struct {
   int B, H, N;
-  int kmax_chunks; /* workgroups per (b,h) of the key-stabiliser pass */
+  int kmax_chunks; /* key-stabiliser partials per (b,h): 9 per chunk of the K'^T V pass */
   int ctx_chunks;  /* token chunks per (b,h) of the K'^T V pass (partials in ws) */
   int apply_chunks;/* token chunks per (b,h) of the output pass */
 } scm_favor_plan;
@@ -99,7 +99,7 @@ int64_t scm_favor_ws_floats(const scm_favor_plan* plan /* host */);
 /* out = attention output; out_centered = out - obar[b,h,:] where obar is the (k'-weighted) mean value vector
  * of the head: kept for the backward, whose denominator path needs it at full relative precision.
  * Saved state of one forward call (caller-allocated):
- *   ctx_bf16 [B*H,288,64] bf16 (centred K'^T V), z [B*H,288] f32, sums [B*H,80] f32 (obar, sum z),
+ *   ctx_bf16 [B*H,288,64] bf16 (centred K'^T V), z [B*H,288] f32, sums [B*H,80] f32 (obar, sum z, key stabiliser),
  *   rowmax [B*H*N] f32, den [B*H*N] f32,
  *   kmax [kmax_chunks*B*H] f32 (partial maxima; their max is the key stabiliser of performer_pytorch.py:90),
  *   kmax_idx [kmax_chunks*B*H] i64 (where each partial maximum sits: (bh*N + n)*512 + feature). */

@@ -47,7 +47,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_nt/bf16", "gemm_nt/f32_bias_res", "gemm_nt/gelu_dual", "gemm_nt/dgelu", "gemm_nt/f32", "gemm_nt/bf16_bias",
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
-    "head_bwd", "colsum_reduce", "prep_omega", "favor_kmax", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
+    "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
     "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
@@ -203,7 +203,7 @@ int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan) {
   plan->apply_chunks = clampi(cus / bh, 1, (N + 31) / 32);
   // context pass: 9-wave workgroups, up to 3 per CU; partial records cost 75 KB each
   plan->ctx_chunks = clampi((2 * cus) / bh, 1, (N + 63) / 64);
-  plan->kmax_chunks = clampi((4 * cus) / bh, 1, (N + 127) / 128);
+  plan->kmax_chunks = NFT * plan->ctx_chunks;   // one key-stabiliser partial per (chunk, wave) of the context pass
   return 0;
 }
 
@@ -227,14 +227,17 @@ int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   SCM_REQ(aligned16(omega_b) && aligned16(ctx_bf16), "scm_favor_fwd: unaligned pointer");
   hipStream_t s = (hipStream_t)stream;
   const int B = plan->B, H = plan->H, N = plan->N;
-  SCM_HIP(favor_kmax(cview(k), omega_b, B, H, N, plan->kmax_chunks, kmax, (long long*)kmax_idx, s), "favor_kmax");
+  SCM_REQ(plan->kmax_chunks == NFT * plan->ctx_chunks, "scm_favor_fwd: plan.kmax_chunks must be 9 * ctx_chunks");
   CtxArgs c{};
   c.x = cview(k); c.y = cview(v); c.omega_b = (const bf16*)omega_b;
-  c.stab = kmax; c.nstab = plan->kmax_chunks * B * H; c.den = nullptr; c.dden = nullptr;
+  c.stab = nullptr; c.nstab = 0; c.den = nullptr; c.dden = nullptr;
+  c.stab_out = kmax; c.key_out = (long long*)kmax_idx;
   c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(0, c, B, plan->ctx_chunks, s), "favor_ctx");
   float* fin = ws + (int64_t)B * H * plan->ctx_chunks * CTX_PART;
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 0, nullptr, ctx_bf16, z, sums, fin, s),
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 0, kmax, plan->kmax_chunks * B * H, (const bf16*)omega_b,
+                             nullptr, ctx_bf16, z,
+                             sums, fin, s),
           "favor_ctx_finalize");
   ApplyArgs a{};
   a.x = cview(q); a.omega_b = (const bf16*)omega_b; a.Mb = (const bf16*)ctx_bf16; a.zf = z; a.sums = sums;
@@ -266,17 +269,18 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   c.dden = dden; c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(1, c, B, plan->ctx_chunks, s), "favor_ctx(dC)");
   float* fin = ws + (int64_t)B * H * plan->ctx_chunks * CTX_PART;
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 1, sums, dctx_bf16, dz, dsums, fin, s),
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 1, nullptr, 0, nullptr, sums, dctx_bf16, dz, dsums, fin, s),
           "favor_ctx_finalize(dC)");
   // 3. key side: dk, dv
   ApplyArgs g{};
   g.x = cview(k); g.y = cview(v); g.omega_b = (const bf16*)omega_b; g.Mb = (const bf16*)dctx_bf16; g.zf = dz;
-  g.sums = dsums; g.stab = kmax; g.nstab = plan->kmax_chunks * B * H; g.out0 = oview(dk); g.out1 = oview(dv);
+  g.sums = dsums; g.out0 = oview(dk); g.out1 = oview(dv);
+  g.stab = sums + DH + 1; g.nstab = 1;   // the global key stabiliser, left there by the forward
   g.H = H; g.N = N;
   g.ksum_part = ws;  // the chunk partials in ws were consumed by the finalize step above
   SCM_HIP(favor_apply(2, g, B, plan->apply_chunks, s), "favor_apply(dk,dv)");
   // 4. gradient through the global key stabiliser lands on one token
-  SCM_HIP(favor_kfix(kmax, (const long long*)kmax_idx, g.nstab, ws, plan->apply_chunks * B * H, omega_b, oview(dk), H,
+  SCM_HIP(favor_kfix(kmax, (const long long*)kmax_idx, plan->kmax_chunks * B * H, ws, plan->apply_chunks * B * H, omega_b, oview(dk), H,
                      N, s), "favor_kfix");
   return 0;
 }

@@ -15,7 +15,6 @@
 // dE'q = dnum C'^T - (dO . (o - obar)) z / den is otherwise a difference of nearly equal terms.
 //
 // Kernels
-//   favor_kmax          max of k.w over the whole local batch -> per-workgroup partial maxima
 //   favor_ctx<MODE>     "feature-stationary": wave w owns features 32w..32w+31 (its slice of the
 //                       projection matrix stays in registers) and accumulates its 32x64 slice of
 //                       sum_n E[n,:]^T y_n over a token chunk.  MODE 0: (k, v) -> C, z.
@@ -126,6 +125,16 @@ __global__ void favor_prep_omega_kernel(const float* __restrict__ omega, bf16* _
 SCM_DEV void argmax_combine(float& v, long long& key, float ov, long long okey) {
   if (ov > v || (ov == v && okey < key)) { v = ov; key = okey; }
 }
+SCM_DEV long long wave_min_key(long long key) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const int lo = __shfl_xor((int)(key & 0xffffffffll), o);
+    const int hi = __shfl_xor((int)(key >> 32), o);
+    const long long ok = ((long long)hi << 32) | (unsigned int)lo;
+    key = ok < key ? ok : key;
+  }
+  return key;
+}
 SCM_DEV void wave_argmax(float& v, long long& key) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -136,63 +145,29 @@ SCM_DEV void wave_argmax(float& v, long long& key) {
   }
 }
 
-// part_val[wg] = max over the workgroup's tokens, part_key[wg] = (bh*N + n) * 512 + feature of the
-// first element attaining it (row-major order of the reference's [B,H,N,M] tensor).
-__global__ __launch_bounds__(256) void favor_kmax_kernel(TensorBHND k, const bf16* __restrict__ omega_b, int H, int N,
-                                                         int chunk_len, float* __restrict__ part_val,
-                                                         long long* __restrict__ part_key) {
-  __shared__ __attribute__((aligned(16))) char omg[NFP * 128];
-  __shared__ float wmax[4];
-  __shared__ long long wkey[4];
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;
-  load_image(omg, omega_b, tid, 256);
-  __syncthreads();
-  const int n_lo = blockIdx.x * chunk_len, n_hi = min(N, n_lo + chunk_len);
-  const bf16* base = k.p + b * k.sb + h * k.sh;
-  float mx = -INFINITY;
-  long long key = 0x7fffffffffffffffll;
-  for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 128) {
-    const int n = n0 + (l & 31);
-    const bool valid = n < n_hi;
-    bf16x8 kf[4];
-    load_token_frags(kf, base + (long)n * k.sn, valid);
-    float m = -INFINITY;
-    int feat = 0;
-#pragma unroll
-    for (int t = 0; t < NFT; ++t) {
-      f32x16 x = score_tile(omg, t, kf);
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (feat_valid(t, r, half) && x[r] > m) { m = x[r]; feat = 32 * t + acc_row(r, half); }
-    }
-    if (valid) argmax_combine(mx, key, m, ((long long)bh * N + n) * 512 + feat);
-  }
-  wave_argmax(mx, key);
-  if (l == 0) { wmax[w] = mx; wkey[w] = key; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int i = 1; i < 4; ++i) argmax_combine(mx, key, wmax[i], wkey[i]);
-    part_val[blockIdx.y * gridDim.x + blockIdx.x] = mx;
-    part_key[blockIdx.y * gridDim.x + blockIdx.x] = key;
-  }
-}
-
 // Gradient through the key stabiliser (torch.max over the whole tensor, performer_pytorch.py:90):
 // dk[b*,h*,n*,:] += -c * (sum over everything of E * dE') * Omega[j*,:] at the argmax element.
-__global__ __launch_bounds__(64) void favor_kfix_kernel(const float* __restrict__ part_val,
-                                                        const long long* __restrict__ part_key, int nstab,
-                                                        const float* __restrict__ ksum_part, int nsum,
-                                                        const bf16* __restrict__ omega_b, TensorBHND_out dk, int H,
-                                                        int N) {
-  const int l = threadIdx.x;
+__global__ __launch_bounds__(256) void favor_kfix_kernel(const float* __restrict__ part_val,
+                                                         const long long* __restrict__ part_key, int nstab,
+                                                         const float* __restrict__ ksum_part, int nsum,
+                                                         const bf16* __restrict__ omega_b, TensorBHND_out dk, int H,
+                                                         int N) {
+  __shared__ float wtot[4], wmx[4];
+  __shared__ long long wkey[4];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   float tot = 0.f;
-  for (int i = l; i < nsum; i += 64) tot += ksum_part[i];
+  for (int i = tid; i < nsum; i += 256) tot += ksum_part[i];
   tot = wave_sum(tot);
   float mx = -INFINITY;
   long long key = 0x7fffffffffffffffll;
-  for (int i = l; i < nstab; i += 64) argmax_combine(mx, key, part_val[i], part_key[i]);
+  for (int i = tid; i < nstab; i += 256) argmax_combine(mx, key, part_val[i], part_key[i]);
   wave_argmax(mx, key);
+  if (l == 0) { wtot[w] = tot; wmx[w] = mx; wkey[w] = key; }
+  __syncthreads();
+  if (w != 0) return;
+  tot = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
+  mx = wmx[0]; key = wkey[0];
+  for (int i = 1; i < 4; ++i) argmax_combine(mx, key, wmx[i], wkey[i]);
   if (!(mx > -INFINITY)) return;
   const int feat = (int)(key & 511);
   const long long tl = key >> 9;
@@ -216,8 +191,14 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
   const bool loader = tid < 512;
   const int lrow = tid >> 3, lch = tid & 7;
 
-  float gstab = 0.f;
-  if (MODE == 0) gstab = reduce_partial_max(a.stab, a.nstab);
+  // MODE 0 (keys): the reference stabilises with ONE max over the whole [B,H,N,M] score tensor
+  // (performer_pytorch.py:89-90).  No separate pass computes it.  Every feature is exponentiated against its own
+  // constant b_m = |w_m|^2 / 2:  exp(c k.w_m - c^2 |k|^2 / 2 - b_m) = exp(-|c k - w_m|^2 / 2) <= 1 for every key,
+  // so nothing can overflow; the waves only TRACK the running max of the raw scores (and where it is attained),
+  // one record per (b,h, chunk, wave), and the chunk reduction applies exp(b_m - c max) per feature once the
+  // global max is known.
+  float lane_max = -INFINITY;   // of the shifted score s - b_m/c, over this lane's feature column
+  int lane_pos = 0;             // 32-token sub-tile (relative to the chunk) where it was first attained
 
   // this wave's slice of the projection matrix as MFMA B operand (k = d, column = feature)
   bf16x8 omf[4];
@@ -228,13 +209,23 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
   }
   const bool lane_feat_valid = (32 * w + (l & 31)) < NF;
   const LaneOffs lo = lane_offs();
+  // b_m / c for this lane's feature: the score accumulator starts there instead of at zero (MODE 0)
+  float sinit = 0.f;
+  if (MODE == 0) {
+    float ss = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float v = (float)omf[ks][j]; ss += v * v; }
+    sinit = -0.5f * xhalf_sum(ss) / CNORM;
+  }
 
   f32x16 cacc[2] = {zero16(), zero16()};
   float zacc = 0.f;
-  float ysum[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ysum[j] = 0.f;
-  float wsum = 0.f;
+  // Feature 266 (the first padding feature) is a "ones" feature: its E is 1 for every token, so its context row
+  // accumulates sum_n y[n,:] and its z slot sum_n w_n -- the plain sums the eps terms need -- inside the same
+  // MFMAs (padding tokens have y = 0 and w = 0).
+  const float padv = (32 * w + (l & 31) == NF) ? 1.f : 0.f;
 
   const bf16* xb = a.x.p + b * a.x.sb + h * a.x.sh;
   const bf16* yb = a.y.p + b * a.y.sb + h * a.y.sh;
@@ -266,18 +257,13 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = (bf16)((float)ys_r[j] * inv);
     }
-    if (val_r) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ysum[j] += (float)yv[j];
-    }
     *(bf16x8*)(buf + img_off(lrow, 8 * lch)) = xs_r;
     *(bf16x8*)(buf + CTX_TILE * 128 + img_off(lrow, 8 * lch)) = yv;
     if (lch == 0) {
-      const float stab = (MODE == 0) ? gstab : st_r;
+      const float stab = (MODE == 0) ? 0.f : st_r;   // MODE 0: the stabiliser is applied by the consuming wave
       float* off = (float*)(buf + 2 * CTX_TILE * 128);
       off[lrow] = val_r ? (HALF_C2 * ss + CNORM * stab) * LOG2E : INFINITY;
       off[CTX_TILE + lrow] = (MODE == 1) ? w_r : (val_r ? 1.f : 0.f);
-      if (MODE == 1) wsum += w_r;
     }
   };
 
@@ -295,9 +281,30 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // S[token, feature] = x_tile (32x64) * Omega_w^T (64x32)
-      f32x16 s = zero16();
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = sinit;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) s = mfma32(*(const bf16x8*)(xs + 4096 * sub + lo.row[ks]), omf[ks], s);
+      if (MODE == 0) {
+        float lm = -INFINITY;   // max of the (shifted) scores over this sub-tile's valid tokens
+        if (n_lo + (it + 1) * CTX_TILE <= n_hi) {   // full tile (wave-uniform): every token counts
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lm = fmaxf(lm, s[r]);
+        } else {                                     // last tile of the chunk: off = inf marks padding rows
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 o4 = *(const f32x4*)(off + 32 * sub + 8 * g + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lm = fmaxf(lm, o4[i] < INFINITY ? s[4 * g + i] : -INFINITY);
+          }
+        }
+        // per-lane running max of this feature's column and the first sub-tile that attained it: no cross-lane
+        // work in the loop (the wave-level argmax is resolved once, after the loop)
+        const bool up = lm > lane_max;
+        lane_max = up ? lm : lane_max;
+        lane_pos = up ? 2 * it + sub : lane_pos;
+      }
       f32x16 e;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = exp2_fast(s[4 * g + i] * (CNORM * LOG2E) - o4[i]);
-          v = lane_feat_valid ? v : 0.f;
+          v = lane_feat_valid ? v : padv;
           e[4 * g + i] = v;
           zacc += v * w4[i];
         }
@@ -332,26 +339,51 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     for (int r = 0; r < 16; ++r) rec[(32 * w + acc_row(r, half)) * DH + 32 * dt + (l & 31)] = cacc[dt][r];
   const float zt = xhalf_sum(zacc);
   if (l < 32) rec[NFP * DH + 32 * w + l] = zt;
-  // fixed-order reduction of the loaders' column sums through the (now idle) tile buffers
-  float* red = (float*)smem;  // [64 rows][64 + 1]
-  if (loader) {
+  if (MODE == 0) {
+    // wave-level argmax: the max of the raw scores, and the first (token, feature) attaining it.  The sub-tile
+    // that holds it is recomputed from global memory with the same MFMA sequence (bit-identical scores).
+    const float lraw = lane_feat_valid ? lane_max - sinit : -INFINITY;
+    const float wm = wave_max(lraw);
+    int pos = (lraw == wm) ? lane_pos : (1 << 30);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[lrow * 65 + 8 * lch + j] = ysum[j];
-    if (lch == 0) red[lrow * 65 + 64] = wsum;
-  }
-  __syncthreads();
-  if (tid <= DH) {
-    float s = 0.f;
-    for (int r = 0; r < CTX_TILE; ++r) s += red[r * 65 + tid];
-    if (tid < DH) rec[NFP * DH + NFP + tid] = s;
-    else rec[NFP * DH + NFP + DH] = (MODE == 1) ? s : (float)max(0, n_hi - n_lo);
+    for (int o = 32; o >= 1; o >>= 1) pos = min(pos, __shfl_xor(pos, o));
+    long long key = 0x7fffffffffffffffll;
+    if (wm > -INFINITY) {
+      const int nbase = n_lo + 32 * pos;
+      const int n = nbase + (l & 31);
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = sinit;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 xf = (n < n_hi) ? *(const bf16x8*)(xb + (long)n * a.x.sn + 16 * ks + 8 * half) : zero_frag();
+        sc = mfma32(xf, omf[ks], sc);
+      }
+      int best = 1 << 30;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) {
+        const bool hit = (sc[r] - sinit == wm) && (nbase + acc_row(r, half) < n_hi);
+        best = hit ? acc_row(r, half) : best;
+      }
+      if (lane_feat_valid && best < (1 << 30))
+        key = ((long long)bh * a.N + nbase + best) * 512 + 32 * w + (l & 31);
+      key = wave_min_key(key);
+    }
+    if (l == 0) {
+      const long slot = ((long)bh * gridDim.x + blockIdx.x) * NFT + w;
+      a.stab_out[slot] = wm;
+      a.key_out[slot] = key;
+    }
   }
 }
 
-// Finalize, stage 1 (grid: bh x 9 feature tiles): sum the chunk partials of 32 features, add the analytic
-// eps terms: M[m,d] = sum_c CE + eps * ysum[d], zz[m] = sum_c zE + eps * wsum.  Writes M (f32), zz and the
-// tile's column sums of M / sum of zz.
+// stab (forward keys only, else null): the per-(b,h, chunk, wave) running maxima of the raw key scores, nstab of
+// them in all.  The partials were taken against the per-feature constant b_m = |w_m|^2 / 2; here they are brought
+// to the reference's stabiliser, the global max: factor exp(b_m - c max(stab)) per feature.
 __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __restrict__ part, int nchunks,
+                                                               const float* __restrict__ stab, int nstab,
+                                                               const bf16* __restrict__ omega_b,
+                                                               float* __restrict__ gmax_out /*sums [bh][80]*/,
                                                                float* __restrict__ M32, float* __restrict__ zz,
                                                                float* __restrict__ colpart /*[bh][9][80]*/) {
   __shared__ float ysum[DH];
@@ -360,14 +392,37 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
   __shared__ float zl[32];
   const int tid = threadIdx.x, bh = blockIdx.x, tile = blockIdx.y;
   const float* base = part + (long)bh * nchunks * CTX_PART;
+  __shared__ float wmaxs[4];
+  float gmax = 0.f;
+  if (stab) {   // max over all partial stabilisers, by the whole workgroup
+    float m = -INFINITY;
+    for (int i = tid; i < nstab; i += 256) m = fmaxf(m, stab[i]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) wmaxs[tid >> 6] = m;
+    __syncthreads();
+    gmax = fmaxf(fmaxf(wmaxs[0], wmaxs[1]), fmaxf(wmaxs[2], wmaxs[3]));
+    if (tile == 0 && tid == 0) gmax_out[(long)bh * SUMS_STRIDE + DH + 1] = gmax;   // for the backward passes
+  }
+  // per-feature factor exp(b_m - c max) of this tile's 32 features (1 when there is no stabiliser: backward)
+  __shared__ float fscale[32];
+  if (tid < 32) {
+    float f = 1.f;
+    if (stab) {
+      const bf16* orow = omega_b + (long)(32 * tile + tid) * DH;
+      float ss = 0.f;
+      for (int d = 0; d < DH; ++d) { const float v = (float)orow[d]; ss += v * v; }
+      f = exp2_fast((0.5f * ss - CNORM * gmax) * LOG2E);
+    }
+    fscale[tid] = f;
+  }
   if (tid < DH) {
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NFP + tid];
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NF * DH + tid];   // row of the ones feature
     ysum[tid] = s;
   }
   if (tid == 64) {
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NFP + DH];
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NF];    // z slot of the ones feature
     wsum = s;
   }
   __syncthreads();
@@ -375,7 +430,7 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
     const int m = 32 * tile + tid;
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + m];
-    const float v = (m < NF) ? s + KEPS * wsum : 0.f;
+    const float v = (m < NF) ? fscale[tid] * s + KEPS * wsum : 0.f;
     zl[tid] = v;
     zz[(long)bh * NFP + m] = v;
   }
@@ -392,7 +447,7 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = 32 * tile + q + 4 * i;
-    const float v = (m < NF) ? acc8[i] + KEPS * ysum[d] : 0.f;
+    const float v = (m < NF) ? fscale[q + 4 * i] * acc8[i] + KEPS * ysum[d] : 0.f;
     M32[((long)bh * NFP + m) * DH + d] = v;
     csum += v;
   }
@@ -772,19 +827,10 @@ hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, int nchunks, float* part,
-                      long long* part_key, hipStream_t s) {
-  const int chunk_len = round_up((N + nchunks - 1) / nchunks, 32);
-  Traced tr(K_KMAX, 0, s, (double)B * H * N * 128);   // k read once
-  hipLaunchKernelGGL(favor_kmax_kernel, dim3(nchunks, B * H), dim3(256), 0, s, k, (const bf16*)omega_b, H, N,
-                     chunk_len, part, part_key);
-  return hipGetLastError();
-}
-
 hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
                       const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s) {
   Traced tr(K_KFIX, 0, s);
-  hipLaunchKernelGGL(favor_kfix_kernel, dim3(1), dim3(64), 0, s, part_val, part_key, nstab, ksum_part, nsum,
+  hipLaunchKernelGGL(favor_kfix_kernel, dim3(1), dim3(256), 0, s, part_val, part_key, nstab, ksum_part, nsum,
                      (const bf16*)omega_b, dk, H, N);
   return hipGetLastError();
 }
@@ -805,13 +851,14 @@ hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
 }
 
 // scratch: BH * (288*64 + 288 + 9*80) floats placed by the caller after the chunk partials
-hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* sums_fwd, void* Mb,
-                              float* zf, float* sums, float* scratch, hipStream_t s) {
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int nstab,
+                              const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s) {
   float* M32 = scratch;
   float* zz = M32 + (long)BH * NFP * DH;
   float* colpart = zz + (long)BH * NFP;
   Traced tr(K_CTX_FINALIZE, 0, s);
-  hipLaunchKernelGGL(favor_ctx_reduce_kernel, dim3(BH, NFT), dim3(256), 0, s, part, nchunks, M32, zz, colpart);
+  hipLaunchKernelGGL(favor_ctx_reduce_kernel, dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+                     omega_b, sums, M32, zz, colpart);
   hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH, NFT), dim3(256), 0, s, M32, zz, colpart, mode, sums_fwd,
                      (bf16*)Mb, zf, sums);
   return hipGetLastError();

@@ -24,8 +24,10 @@ struct CtxArgs {
   TensorBHND x;          // MODE 0: k ; MODE 1: q
   TensorBHND y;          // MODE 0: v ; MODE 1: dO
   const bf16* omega_b;   // [288][64]
-  const float* stab;     // MODE 0: kmax partials ; MODE 1: rowmax [B*H*N]
+  const float* stab;     // MODE 1: rowmax [B*H*N]
   int nstab;
+  float* stab_out;       // MODE 0: [B*H][chunks][9] running maxima of k.w, one per wave (its 32 features)
+  long long* key_out;    // MODE 0: where each was attained: (bh*N + n)*512 + feature
   const float* den;      // MODE 1: [B*H*N]
   const float* dden;     // MODE 1: [B*H*N]
   int H, N, chunk_len;   // chunk_len % 64 == 0
@@ -59,7 +61,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_GEMM_NT = 0,            // gemm_nt_kernel, + epilogue id (6 consecutive ids)
   K_GEMM_SKINNY = 6,        // gemm_skinny_kernel, + epilogue id (6 consecutive ids)
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
-  K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_KMAX, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
+  K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
   K_APPLY_BWD_K, K_KFIX, K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
@@ -104,14 +106,12 @@ hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, i
 
 // favor.hip
 hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s);
-hipError_t favor_kmax(TensorBHND k, const void* omega_b, int B, int H, int N, int nchunks, float* part,
-                      long long* part_key, hipStream_t s);
 hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
                       const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s);
 hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s);
 constexpr int CTX_FIN_SCRATCH = NFP * DH + NFP + NFT * SUMS_STRIDE;  // floats per (b,h) of finalize scratch
-hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* sums_fwd, void* Mb,
-                              float* zf, float* sums, float* scratch, hipStream_t s);
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int nstab,
+                              const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s);
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s);
 
 }  // namespace scm
