@@ -30,6 +30,10 @@
 namespace scm {
 
 constexpr int STAGE_PITCH = 68;                     // floats per staged output row (64 + 4 spare)
+// favor_apply LDS: Omega and context images, z, sums, 8 output stages; then 8 x 1 KB of junk for the
+// prefetch-by-touch copies
+constexpr int APPLY_LDS_MAIN = 2 * NFP * 128 + (NFP + SUMS_STRIDE) * 4 + 8 * 32 * STAGE_PITCH * 4;
+constexpr int APPLY_LDS = APPLY_LDS_MAIN + 8 * 1024;
 
 SCM_DEV void load_image(char* img, const bf16* __restrict__ src /*[288][64]*/, int tid, int nthreads) {
   for (int c = tid; c < NFP * 8; c += nthreads) {
@@ -56,6 +60,16 @@ SCM_DEV void load_token_frags(bf16x8 (&f)[4], const bf16* __restrict__ row, bool
   const int half = lane_id() >> 5;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) f[ks] = valid ? *(const bf16x8*)(row + 16 * ks + 8 * half) : zero_frag();
+}
+
+// Touch the 128-byte rows of the 32 tokens that the NEXT iteration of this wave will load: an asynchronous
+// global->LDS copy of 16 bytes per lane (lane halves cover both 64-byte halves of a row) into a junk area that is
+// never read.  The lines are then in L2 when the real fragment loads arrive, which turns their HBM latency into an
+// L2 hit without staging registers.  `after` orders the copy behind the loads the current iteration has already
+// consumed: memory operations complete in issue order, so a copy issued before them would delay them.
+SCM_DEV void warm_rows(u32x4 rsrc, uint32_t junk_lds, uint32_t voffset, float after) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(junk_lds), "v"(voffset), "s"(rsrc), "v"(after) : "memory");
 }
 
 SCM_DEV float frag_sumsq(const bf16x8 (&f)[4]) {
@@ -595,6 +609,20 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
   const long srow = (long)bh * a.N;
   float ksum = 0.f;  // MODE 2: sum over this wave's tokens of sum_m dA
   const LaneOffs lo = lane_offs();
+  // prefetch-by-touch of the next tile's rows (see warm_rows): one resource per streamed tensor of this (b,h)
+  const uint32_t junk = lds_addr_of(smem) + (uint32_t)APPLY_LDS_MAIN + 1024 * __builtin_amdgcn_readfirstlane(w);
+  const u32x4 rx = dma_rsrc(xb, (uint32_t)(((long)(a.N - 1) * a.x.sn + DH) * 2));
+  const bf16* yb_ = (MODE != 0) ? a.y.p + b * a.y.sb + h * a.y.sh : xb;
+  const bf16* y2b_ = (MODE == 1) ? a.y2.p + b * a.y2.sb + h * a.y2.sh : xb;
+  const u32x4 ry = dma_rsrc(yb_, (uint32_t)(((long)(a.N - 1) * a.y.sn + DH) * 2));
+  const u32x4 ry2 = dma_rsrc(y2b_, (uint32_t)(((long)(a.N - 1) * a.y2.sn + DH) * 2));
+  auto warm_next = [&](int n, float after) {
+    const int nn = n + 256;
+    const bool nv = nn < n_hi;
+    warm_rows(rx, junk, nv ? (uint32_t)((long)nn * a.x.sn + 32 * half) * 2 : BUF_OOB, after);
+    if (MODE != 0) warm_rows(ry, junk, nv ? (uint32_t)((long)nn * a.y.sn + 32 * half) * 2 : BUF_OOB, after);
+    if (MODE == 1) warm_rows(ry2, junk, nv ? (uint32_t)((long)nn * a.y2.sn + 32 * half) * 2 : BUF_OOB, after);
+  };
 
   for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 256) {
     const int n = n0 + (l & 31);
@@ -604,6 +632,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
     const float norm2 = frag_sumsq(xf);
 
     if (MODE == 0) {
+      warm_next(n, norm2);
       f32x16 X[NFT];
       float mx = -INFINITY;
 #pragma unroll
@@ -675,6 +704,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) dof[ks][j] = (bf16)((float)dof[ks][j] * inv);
       const float off = (HALF_C2 * norm2 + CNORM * rmx) * LOG2E;
+      warm_next(n, off + dden);
       f32x16 Y[2] = {zero16(), zero16()};
       float rs = 0.f, rsm = 0.f;
       int jstar = 1 << 20;
@@ -743,6 +773,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       bf16x8 vf[4];
       load_token_frags(vf, vb + (long)n * a.y.sn, valid);
       const float off = (HALF_C2 * norm2 + CNORM * gstab) * LOG2E;
+      warm_next(n, off + (float)vf[3][7]);
       f32x16 Yk[2] = {zero16(), zero16()};
       f32x16 Yv[2] = {zero16(), zero16()};
       float rs = 0.f;
@@ -864,7 +895,7 @@ hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, 
   return hipGetLastError();
 }
 
-size_t favor_apply_lds() { return 2 * NFP * 128 + (NFP + SUMS_STRIDE) * 4 + 8 * 32 * STAGE_PITCH * 4; }
+size_t favor_apply_lds() { return APPLY_LDS; }
 
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s) {
   a.chunk_len = round_up((a.N + nchunks - 1) / nchunks, 32);
