@@ -201,8 +201,8 @@ int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan) {
   plan->B = B; plan->H = H; plan->N = N;
   // output pass: one 8-wave workgroup per CU (LDS bound) -> at most one round of workgroups
   plan->apply_chunks = clampi(cus / bh, 1, (N + 31) / 32);
-  // context pass: 9-wave workgroups, up to 3 per CU; partial records cost 75 KB each
-  plan->ctx_chunks = clampi((2 * cus) / bh, 1, (N + 63) / 64);
+  // context pass: 9-wave workgroups, one resident per CU (register bound): one round; partial records cost 75 KB each
+  plan->ctx_chunks = clampi(cus / bh, 1, (N + 63) / 64);
   plan->kmax_chunks = NFT * plan->ctx_chunks;   // one key-stabiliser partial per (chunk, wave) of the context pass
   return 0;
 }

@@ -49,3 +49,25 @@ for name, fn, flops, by in cases:
     if filt and filt not in name: continue
     dt = timeit(fn)
     print(f"{name:32s} {dt*1e6:8.1f} us  {flops/dt/1e12:7.1f} TFLOP/s  {by/dt/1e12:5.2f} TB/s")
+
+# ---- FAVOR+ attention passes (per-kernel times from the library's event trace)
+if not filt or "favor" in filt:
+    B, N = 3, 16906
+    qkv = (torch.randn(B, N, 3, H, 64, device=dev) * 0.5).to(bf)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    omega = ops.prep_omega(torch.randn(266, 64, device=dev) * 1.0)
+    o = torch.empty(B, N, H, 64, dtype=bf, device=dev); oc = torch.empty_like(o)
+    do = (torch.randn(B, N, H, 64, device=dev) * 0.1).to(bf)
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    def run():
+        sv = ops.favor_fwd(q, k, v, omega, o.permute(0, 2, 1, 3), oc.permute(0, 2, 1, 3))
+        ops.favor_bwd(q, k, v, oc.permute(0, 2, 1, 3), do.permute(0, 2, 1, 3), omega, sv, dq, dk, dv)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    ops.trace_collect(); ops.trace_enable("all")
+    reps = 10
+    for _ in range(reps): run()
+    torch.cuda.synchronize(); ops.trace_enable(None)
+    for name, (ms, fl, cnt, by) in sorted(ops.trace_collect().items(), key=lambda kv: -kv[1][0]):
+        print(f"{name:32s} {ms / cnt * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  {by / (ms * 1e-3) / 1e12:5.2f} TB/s")
