@@ -101,7 +101,6 @@ def main():
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4)
-    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=6, reduction="mean")
     # Gradient accumulation over the grad_acc micro-steps: backward hands each parameter a fresh gradient
     # (p.grad is None, so autograd stores it without an add kernel) and ONE multi-tensor add folds all of them into
     # static accumulators; the accumulators become p.grad for the all-reduce / clip / Adam of the sync step.
@@ -116,8 +115,8 @@ def main():
 
     def micro_step():
         """mask -> encoder forward -> CE -> backward (gradients accumulate), s1_pretrain_rna.py:290-302"""
-        masked, labels = s1.data_mask(static_tok, 0.15, 0.9, 6, 6)
-        loss = loss_fn(model(masked).transpose(1, 2), labels) / args.grad_acc
+        masked, labels = s1.data_mask_device(static_tok, 0.15, 0.9, 6, 6)
+        loss = s1.masked_cross_entropy(model(masked), labels, 6) / args.grad_acc
         loss.backward()
         torch._foreach_add_(accs, [p.grad for p in params])
         for p in params:

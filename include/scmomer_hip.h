@@ -129,6 +129,24 @@ int scm_head_bwd(const float* dout, const float* denc, const float* out, const f
                  int relu, float* dx, void* dx_bf16, float* ws, float* dgamma, float* dbeta, float* dW, float* db,
                  int accumulate, void* stream);
 
+/* ---- S1 masked-autoencoding step tail: s1_pretrain_rna.py:88-121 (data_mask, get_mask_subset_with_prob,
+ *      mask_with_tokens, prob_mask_like) and :268,297 (CrossEntropyLoss(ignore_index, mean)) ------------------ */
+/* Per cell (row of tokens [B,N], int64): tokens 0 and pad_id are never maskable; the ceil(f32(count) * mask_prob)
+ * maskable positions with the largest rand_pick draws are picked (at most max_masked = ceil(mask_prob * N); equal
+ * draws at the boundary: lowest positions first); picked positions with rand_replace < replace_prob become
+ * mask_id in masked_input; labels = token at picked positions, pad_id elsewhere.  Draws are f32 in [0,1). */
+int scm_s1_mask(const int64_t* tokens, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,
+                float replace_prob, int max_masked, int64_t pad_id, int64_t mask_id, int64_t* masked_input,
+                int64_t* labels, void* stream);
+/* loss_count[0] = mean over tokens with label != ignore_index of -log softmax(logits[t,:])[label[t]],
+ * loss_count[1] = number of such tokens (f32).  logits f32 [T,C], C <= 8.  ws: scm_ce_ws_floats(T) floats. */
+int64_t scm_ce_ws_floats(int64_t T);
+int scm_ce_fwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, float* ws,
+               float* loss_count, void* stream);
+/* dlogits = d loss / d logits * dloss[0] (dloss: device scalar, the incoming gradient of the loss). */
+int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, const float* dloss,
+               const float* loss_count, float* dlogits, void* stream);
+
 /* ---- measurement aid (no reference counterpart): per-kernel durations from HIP events recorded on the
  *      launch stream around each launch of the selected kernel.  scm_trace_enable(kid): -1 off,
  *      scm_trace_kernel_count() = every kernel, else one kernel id.  scm_trace_collect waits for the recorded

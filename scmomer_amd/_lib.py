@@ -50,6 +50,10 @@ SIGNATURES = {
     "scm_trace_enable": (i32, [i32]),
     "scm_trace_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_int64)]),
+    "scm_s1_mask": (i32, [vp, vp, vp, i32, i32, C.c_float, C.c_float, i32, i64, i64, vp, vp, vp]),
+    "scm_ce_ws_floats": (i64, [i64]),
+    "scm_ce_fwd": (i32, [vp, vp, i64, i32, i64, vp, vp, vp]),
+    "scm_ce_bwd": (i32, [vp, vp, i64, i32, i64, vp, vp, vp, vp]),
     "scm_head_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
     "scm_head_bwd_ws_floats": (i64, [i64, i32, i32]),
     "scm_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -48,7 +48,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -282,6 +282,37 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   // 4. gradient through the global key stabiliser lands on one token
   SCM_HIP(favor_kfix(kmax, (const long long*)kmax_idx, plan->kmax_chunks * B * H, ws, plan->apply_chunks * B * H, omega_b, oview(dk), H,
                      N, s), "favor_kfix");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- S1 step tail
+int scm_s1_mask(const int64_t* tokens, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,
+                float replace_prob, int max_masked, int64_t pad_id, int64_t mask_id, int64_t* masked_input,
+                int64_t* labels, void* stream) {
+  SCM_REQ(tokens && rand_pick && rand_replace && masked_input && labels, "scm_s1_mask: null pointer");
+  SCM_REQ(B > 0 && N > 0 && (int64_t)B * N < (1ll << 31), "scm_s1_mask: bad sizes");
+  SCM_REQ(mask_prob >= 0.f && mask_prob <= 1.f && replace_prob >= 0.f && replace_prob <= 1.f && max_masked >= 0,
+          "scm_s1_mask: probabilities must be in [0,1]");
+  SCM_HIP(s1_mask(tokens, rand_pick, rand_replace, B, N, mask_prob, replace_prob, max_masked, pad_id, mask_id,
+                  masked_input, labels, (hipStream_t)stream), "scm_s1_mask");
+  return 0;
+}
+
+int64_t scm_ce_ws_floats(int64_t T) { return 2 * (int64_t)ce_blocks(T); }
+
+int scm_ce_fwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, float* ws,
+               float* loss_count, void* stream) {
+  SCM_REQ(logits && labels && ws && loss_count, "scm_ce_fwd: null pointer");
+  SCM_REQ(T > 0 && C > 0 && C <= 8, "scm_ce_fwd: need 1 <= C <= 8");
+  SCM_HIP(ce_fwd(logits, labels, T, C, ignore_index, ws, loss_count, (hipStream_t)stream), "scm_ce_fwd");
+  return 0;
+}
+
+int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, const float* dloss,
+               const float* loss_count, float* dlogits, void* stream) {
+  SCM_REQ(logits && labels && dloss && loss_count && dlogits, "scm_ce_bwd: null pointer");
+  SCM_REQ(T > 0 && C > 0 && C <= 8, "scm_ce_bwd: need 1 <= C <= 8");
+  SCM_HIP(ce_bwd(logits, labels, T, C, ignore_index, dloss, loss_count, dlogits, (hipStream_t)stream), "scm_ce_bwd");
   return 0;
 }
 

@@ -1,0 +1,224 @@
+// The two ends of the S1 masked-autoencoding step that sit around the encoder:
+//
+//  s1_mask   : data_mask / get_mask_subset_with_prob / mask_with_tokens / prob_mask_like
+//              (s1_pretrain_rna.py:88-121): per cell, the ceil(mask_prob * #maskable) maskable positions
+//              with the largest uniform draws are picked; tokens 0 and pad are never maskable;
+//              picked positions whose second draw is below replace_prob become the mask token; labels hold
+//              the original token at picked positions and pad elsewhere.  Index work: bit-exact.
+//  ce_fwd/bwd: CrossEntropyLoss(ignore_index, reduction='mean') on the [T, C<=8] logits
+//              (s1_pretrain_rna.py:268,297) and its gradient.
+#include "scm_launch.hpp"
+
+namespace scm {
+
+// ------------------------------------------------------------------------------------------
+// s1_mask: one 1024-thread workgroup per cell.  The k-th largest draw among the maskable positions is found by
+// a 4 x 8-bit radix select on the float bits (draws are in [0,1): the unsigned order of the bits is the order
+// of the values); draws above it are picked, and of the draws equal to it the lowest positions, as many as are
+// still needed.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void s1_mask_kernel(const int64_t* __restrict__ tok,
+                                                       const float* __restrict__ rand_pick,
+                                                       const float* __restrict__ rand_replace, int N,
+                                                       float mask_prob, float replace_prob, int max_masked,
+                                                       long long pad_id, long long mask_id,
+                                                       int64_t* __restrict__ masked, int64_t* __restrict__ labels) {
+  __shared__ int hist[256];
+  __shared__ int sh_count, sh_prefix, sh_need, sh_tiebase;
+  __shared__ int wave_cnt[16];
+  const int tid = threadIdx.x;
+  const long base = (long)blockIdx.x * N;
+  const int64_t* t = tok + base;
+  const float* rp = rand_pick + base;
+  const float* rr = rand_replace + base;
+
+  // 1. number of maskable positions
+  if (tid == 0) sh_count = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = tid; i < N; i += 1024) c += (t[i] != 0 && t[i] != pad_id) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+  if ((tid & 63) == 0) atomicAdd(&sh_count, c);
+  __syncthreads();
+  const int count = sh_count;
+  // ceil(count * prob) in float32, as (num_tokens * prob).ceil() evaluates it; at most ceil(prob * N) are kept
+  int k = (int)ceilf((float)count * mask_prob);
+  k = min(k, max_masked);
+  k = min(k, count);
+
+  // 2. radix select: after the passes, `prefix` holds the bits of the k-th largest key
+  unsigned prefix = 0;
+  int need = k;   // how many are still wanted among the keys that match the prefix so far
+  if (k > 0) {
+    for (int pass = 3; pass >= 0; --pass) {
+      const int shift = 8 * pass;
+      const unsigned himask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < N; i += 1024) {
+        if (t[i] != 0 && t[i] != pad_id) {
+          const unsigned key = __float_as_uint(rp[i]);
+          if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+      }
+      __syncthreads();
+      if (tid < 256) {  // the digit d with  #(keys of a larger digit) < need <= #(keys of digit >= d)
+        int above_d = 0;
+        for (int j = tid + 1; j < 256; ++j) above_d += hist[j];
+        const int mine = hist[tid];
+        if (above_d < need && need <= above_d + mine) {
+          sh_prefix = (int)(prefix | ((unsigned)tid << shift));
+          sh_need = need - above_d;
+        }
+      }
+      __syncthreads();
+      prefix = (unsigned)sh_prefix;
+      need = sh_need;
+      __syncthreads();
+    }
+  }
+  // now: keys > prefix are all picked; `need` of the keys == prefix are picked, lowest positions first
+
+  // 3. write-out in position order, ranking the ties with a workgroup prefix count
+  if (tid == 0) sh_tiebase = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < N; i0 += 1024) {
+    const int i = i0 + tid;
+    long long tv = 0;
+    bool maskable = false, above = false, tie = false;
+    if (i < N) {
+      tv = t[i];
+      maskable = (tv != 0 && tv != pad_id) && k > 0;
+      const unsigned key = __float_as_uint(rp[i]);
+      above = maskable && key > prefix;
+      tie = maskable && key == prefix;
+    }
+    // rank of this tie among the ties of the chunk (position order)
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(tie);
+    const int lane = tid & 63, wv = tid >> 6;
+    const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv] = __builtin_popcountll(bal);
+    __syncthreads();
+    int wbase = sh_tiebase;
+    for (int j = 0; j < wv; ++j) wbase += wave_cnt[j];
+    const bool picked = above || (tie && (wbase + before) < need);
+    if (i < N) {
+      const bool rep = rr[i] < replace_prob;
+      masked[base + i] = (picked && rep) ? mask_id : tv;
+      labels[base + i] = picked ? tv : pad_id;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int j = 0; j < 16; ++j) tot += wave_cnt[j];
+      sh_tiebase += tot;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// cross entropy over C <= 8 classes, mean over the tokens whose label is not `ignore`
+// ------------------------------------------------------------------------------------------
+constexpr int CE_MAXC = 8;
+
+// partial[block] = { sum of -log softmax(logits)[label], number of counted tokens }
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits,
+                                                     const int64_t* __restrict__ labels, long T, int C,
+                                                     long long ignore, float* __restrict__ partial) {
+  __shared__ float rs[4], rc[4];
+  float s = 0.f, cnt = 0.f;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < T; t += (long)gridDim.x * 256) {
+    const long long lab = labels[t];
+    if (lab == ignore) continue;
+    float v[CE_MAXC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c) {
+      v[c] = c < C ? logits[t * C + c] : -INFINITY;
+      m = fmaxf(m, v[c]);
+    }
+    float se = 0.f, pick = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c) {
+      se += c < C ? expf(v[c] - m) : 0.f;
+      pick = (c == (int)lab) ? v[c] : pick;
+    }
+    s += (m + logf(se)) - pick;
+    cnt += 1.f;
+  }
+  s = wave_sum(s);
+  cnt = wave_sum(cnt);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { rs[w] = s; rc[w] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    partial[2 * blockIdx.x + 1] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+  }
+}
+
+// out[0] = loss = sum / count (nan when nothing is counted, as torch), out[1] = count
+__global__ __launch_bounds__(64) void ce_finalize_kernel(const float* __restrict__ partial, int nblocks,
+                                                         float* __restrict__ out) {
+  float s = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+  s = wave_sum(s);
+  c = wave_sum(c);
+  if (threadIdx.x == 0) { out[0] = s / c; out[1] = c; }
+}
+
+// dlogits[t][c] = (softmax(logits[t])[c] - [c == label]) * dloss / count for counted tokens, else 0
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits,
+                                                     const int64_t* __restrict__ labels, long T, int C,
+                                                     long long ignore, const float* __restrict__ dloss,
+                                                     const float* __restrict__ loss_count,
+                                                     float* __restrict__ dlogits) {
+  const float scale = dloss[0] / loss_count[1];
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < T; t += (long)gridDim.x * 256) {
+    const long long lab = labels[t];
+    float v[CE_MAXC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c) {
+      v[c] = c < C ? logits[t * C + c] : -INFINITY;
+      m = fmaxf(m, v[c]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c) { v[c] = c < C ? expf(v[c] - m) : 0.f; se += v[c]; }
+    const float inv = (lab == ignore) ? 0.f : scale / se;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c)
+      if (c < C) dlogits[t * C + c] = (lab == ignore) ? 0.f : (v[c] * inv - ((c == (int)lab) ? scale : 0.f));
+  }
+}
+
+// ---------------------------------------------------------------- host launchers
+hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,
+                   float replace_prob, int max_masked, long long pad_id, long long mask_id, int64_t* masked,
+                   int64_t* labels, hipStream_t s) {
+  Traced tr(K_S1_MASK, 0, s);
+  hipLaunchKernelGGL(s1_mask_kernel, dim3(B), dim3(1024), 0, s, tok, rand_pick, rand_replace, N, mask_prob,
+                     replace_prob, max_masked, pad_id, mask_id, masked, labels);
+  return hipGetLastError();
+}
+int ce_blocks(long T) { long b = (T + 255) / 256; return (int)(b < 256 ? (b < 1 ? 1 : b) : 256); }
+hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, float* partial,
+                  float* out, hipStream_t s) {
+  Traced tr(K_CE, 0, s);
+  const int nb = ce_blocks(T);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, s, logits, labels, T, C, ignore, partial);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, out);
+  return hipGetLastError();
+}
+hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, const float* dloss,
+                  const float* loss_count, float* dlogits, hipStream_t s) {
+  Traced tr(K_CE, 0, s);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(T)), dim3(256), 0, s, logits, labels, T, C, ignore, dloss,
+                     loss_count, dlogits);
+  return hipGetLastError();
+}
+
+}  // namespace scm

@@ -62,7 +62,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_GEMM_SKINNY = 6,        // gemm_skinny_kernel, + epilogue id (6 consecutive ids)
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
-  K_APPLY_BWD_K, K_KFIX, K_COUNT
+  K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
@@ -103,6 +103,16 @@ hipError_t colsum_reduce(const float* partial, int nblocks, int width, const Col
                          hipStream_t s);
 hipError_t colsum_reduce(const float* partial, int nblocks, int width, int lo, int hi, float* out, int accumulate,
                          hipStream_t s);
+
+// s1_tail.hip
+hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,
+                   float replace_prob, int max_masked, long long pad_id, long long mask_id, int64_t* masked,
+                   int64_t* labels, hipStream_t s);
+int ce_blocks(long T);
+hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, float* partial,
+                  float* out, hipStream_t s);
+hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, const float* dloss,
+                  const float* loss_count, float* dlogits, hipStream_t s);
 
 // favor.hip
 hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s);

@@ -249,6 +249,43 @@ def head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, w, relu: bool, dgamma,
     return (dx, dxb) if with_bf16 else dx
 
 
+# ----------------------------------------------------------------------------- S1 step tail
+def s1_mask(tokens: torch.Tensor, rand_pick: torch.Tensor, rand_replace: torch.Tensor, mask_prob: float,
+            replace_prob: float, pad_id: int, mask_id: int):
+    """-> (masked_input, labels), int64 [B,N]"""
+    import math
+    _req(tokens, torch.int64, "tokens")
+    _req(rand_pick, F32, "rand_pick")
+    _req(rand_replace, F32, "rand_replace")
+    b, n = tokens.shape
+    masked = torch.empty_like(tokens)
+    labels = torch.empty_like(tokens)
+    check(lib.scm_s1_mask(_p(tokens), _p(rand_pick), _p(rand_replace), b, n, mask_prob, replace_prob,
+                          math.ceil(mask_prob * n), pad_id, mask_id, _p(masked), _p(labels), _stream()), "scm_s1_mask")
+    return masked, labels
+
+
+def ce_fwd(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int) -> torch.Tensor:
+    """-> f32 [2] = (mean loss over counted tokens, number of counted tokens)"""
+    _req(logits, F32, "logits")
+    _req(labels, torch.int64, "labels")
+    c = logits.shape[-1]
+    t = logits.numel() // c
+    ws = torch.empty(lib.scm_ce_ws_floats(t), dtype=F32, device=logits.device)
+    out = torch.empty(2, dtype=F32, device=logits.device)
+    check(lib.scm_ce_fwd(_p(logits), _p(labels), t, c, ignore_index, _p(ws), _p(out), _stream()), "scm_ce_fwd")
+    return out
+
+
+def ce_bwd(logits, labels, ignore_index: int, dloss: torch.Tensor, loss_count: torch.Tensor) -> torch.Tensor:
+    c = logits.shape[-1]
+    t = logits.numel() // c
+    dlogits = torch.empty_like(logits)
+    check(lib.scm_ce_bwd(_p(logits), _p(labels), t, c, ignore_index, _p(dloss), _p(loss_count), _p(dlogits),
+                         _stream()), "scm_ce_bwd")
+    return dlogits
+
+
 # ----------------------------------------------------------------------------- per-kernel timing
 def trace_kernel_names():
     return [lib.scm_trace_kernel_name(i).decode() for i in range(lib.scm_trace_kernel_count())]

@@ -67,6 +67,47 @@ def data_mask(data: torch.Tensor, mask_prob: float, replace_prob: float, pad_tok
     return masked_input, labels
 
 
+def data_mask_device(data: torch.Tensor, mask_prob: float, replace_prob: float, pad_token_id: int, mask_token_id: int,
+                     rand_pick: Optional[torch.Tensor] = None,
+                     rand_replace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """data_mask as ONE kernel (a radix select per cell instead of a 16,906-wide topk and a dozen elementwise
+    passes).  Same draws, same order and same result as data_mask; draws that tie exactly at the k-th value are
+    resolved lowest position first (torch.topk leaves that order unspecified)."""
+    from . import ops
+    if rand_pick is None:
+        rand_pick = torch.rand(data.shape, device=data.device)
+    if rand_replace is None:
+        rand_replace = torch.zeros_like(data).float().uniform_(0, 1)
+    return ops.s1_mask(data.contiguous(), rand_pick.contiguous(), rand_replace.contiguous(), mask_prob, replace_prob,
+                       pad_token_id, mask_token_id)
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        from . import ops
+        lg = logits.contiguous()
+        lb = labels.contiguous()
+        out = ops.ce_fwd(lg, lb, ignore_index)
+        ctx.save_for_backward(lg, lb, out)
+        ctx.ignore_index = ignore_index
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        from . import ops
+        lg, lb, out = ctx.saved_tensors
+        d = ops.ce_bwd(lg, lb, ctx.ignore_index, dloss.to(torch.float32).contiguous(), out)
+        return d, None, None
+
+
+def masked_cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int) -> torch.Tensor:
+    """CrossEntropyLoss(ignore_index=..., reduction='mean')(logits.transpose(1, 2), labels) of the S1 loop
+    (s1_pretrain_rna.py:268,297) on the un-transposed f32 logits [B, N, C<=8]: two small kernels forward, one
+    backward."""
+    return _MaskedCE.apply(logits, labels, ignore_index)
+
+
 def synthetic_tokens(seed: int, batch: int, n: int, device=None) -> torch.Tensor:
     """Synthetic S1 cells: 15 % expressed genes with gamma(2, 1.2) log-expression, S1 binning."""
     import numpy as np
