@@ -8,5 +8,8 @@ from . import _lib  # noqa: F401  (raises if the HIP library is missing: there i
 from .performer import (FastAttention, FeedForward, Gene2VecPositionalEmbedding, Performer, PerformerLM,
                         PreLayerNorm, SelfAttention, SequentialSequence, gaussian_orthogonal_random_matrix)
 
-__all__ = ["FastAttention", "FeedForward", "Gene2VecPositionalEmbedding", "Performer", "PerformerLM",
+from .rna_encoder import Identity  # noqa: E402,F401
+from .scmomer import StudentEncoder, scMomer  # noqa: E402,F401
+
+__all__ = ["Identity", "StudentEncoder", "scMomer", "FastAttention", "FeedForward", "Gene2VecPositionalEmbedding", "Performer", "PerformerLM",
            "PreLayerNorm", "SelfAttention", "SequentialSequence", "gaussian_orthogonal_random_matrix"]

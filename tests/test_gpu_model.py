@@ -187,3 +187,33 @@ def test_full_size_forward_vs_oracle():
     assert relmax(out, ref) < TOL_MAX and rell2(out, ref) < TOL_L2
     # tokens 0..5 only, mask positions get the argmax class like the reference's accuracy metric
     assert (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean() > 0.97
+
+
+def test_scmomer_cell_embedding_matches_reference_fixture(golden_dir):
+    """scMomer.get_cell_embedding (RNA-only configuration, 16906 genes, depth 6) on the kernels vs the output of
+    the reference itself on the same seeded parameters.  Stated bf16 tolerance: relative L2 <= 4e-3, max-abs error
+    <= 6e-3 of the output's max-abs (the 16906-wide projections average the per-gene bf16 rounding down)."""
+    import types
+    import scmomer_amd as S
+    from oracle import performer_oracle as O
+    g = np.load(os.path.join(golden_dir, "scmomer_embed.npz"))
+    seed = int(g["seed"])
+    p = O.make_scmomer_params(seed)
+    for k in g.files:
+        if k.startswith("param:"):
+            p[k[len("param:"):]] = torch.from_numpy(g[k])
+    cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+    m = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(16906, 128))
+    m.load_state_dict(p, strict=True)
+    m = m.to("cuda").eval()
+    for q in m.parameters():
+        q.requires_grad = False
+    cells = torch.from_numpy(O.synthetic_cells(seed, 2, 16906)).to("cuda")
+    with torch.no_grad():
+        emb = m.get_cell_embedding(cells).cpu()
+        per_gene = m.rna_model(torch.round(cells).long().clamp(min=0, max=5)).cpu()
+    want = torch.from_numpy(g["embedding"])
+    assert float((emb - want).norm() / want.norm()) <= 4e-3
+    assert float((emb - want).abs().max()) <= 6e-3 * float(want.abs().max())
+    pg = torch.from_numpy(g["per_gene_sample"])
+    assert float((per_gene[:, ::97] - pg).norm() / pg.norm()) <= 4e-3

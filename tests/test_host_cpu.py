@@ -138,3 +138,23 @@ def test_redraw_bookkeeping():
     for _ in range(5):
         m.performer.check_redraw_projections()
     assert torch.equal(fixed, m.performer.net.layers[0][0].fn.fast_attention.projection_matrix)
+
+
+def test_scmomer_wrapper_layout_and_errors():
+    """state_dict keys of the RNA-only scMomer wrapper are the reference's (scmomer.py:21-39); the ATAC branch is
+    refused loudly"""
+    import types
+    from oracle import performer_oracle as O
+    cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+    m = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(16906, 128))
+    want = O.make_scmomer_params(1)
+    got = m.state_dict()
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert tuple(got[k].shape) == tuple(v.shape) and got[k].dtype == v.dtype, k
+    with pytest.raises(NotImplementedError):
+        S.scMomer(cfg, atac_config=object())
+    with pytest.raises(NotImplementedError):
+        m(rna_values=torch.zeros(1, 16906), mode="multimodal")
+    with pytest.raises(ValueError):
+        m(rna_values=torch.zeros(1, 16906), mode="other")

@@ -122,3 +122,19 @@ def test_projection_matrix_construction(golden_dir):
     torch.manual_seed(int(g["seed"]))
     again = O.gaussian_orthogonal_random_matrix(266, 64, None).numpy()
     np.testing.assert_allclose(again, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_scmomer_cell_embedding(golden_dir):
+    """scMomer.get_cell_embedding of the reference (RNA-only configuration, 16906 genes, depth 6) vs the oracle's
+    restatement, same seeded parameters: fp32 against fp32."""
+    g = np.load(os.path.join(golden_dir, "scmomer_embed.npz"))
+    seed = int(g["seed"])
+    p = O.make_scmomer_params(seed)
+    for k in g.files:
+        if k.startswith("param:"):
+            p[k[len("param:"):]] = torch.from_numpy(g[k])
+    cells = torch.from_numpy(O.synthetic_cells(seed, 2, 16906))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        emb = O.scmomer_cell_embedding(cells, p)
+    np.testing.assert_allclose(emb.numpy(), g["embedding"], rtol=2e-4, atol=2e-5)

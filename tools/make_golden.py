@@ -159,6 +159,31 @@ def main():
     ref_proj = pp.gaussian_orthogonal_random_matrix(266, 64)
     np.savez_compressed(os.path.join(out, "projection.npz"), seed=np.int64(2024), proj=ref_proj.numpy())
 
+    # ---- (x) scMomer.get_cell_embedding, RNA-only configuration, full gene count ---------------
+    # (scmomer.py hard-codes 16906 genes and depth 6; the student encoder is the one of extract_cell_emb.py)
+    import model.scmomer as sm
+    seed = 4242
+    state["rows"] = 16906
+    p = O.make_scmomer_params(seed)
+    enc = torch.nn.Module()
+    enc.encoder = torch.nn.Sequential(torch.nn.Linear(16906, 256), torch.nn.LayerNorm(256), torch.nn.GELU(),
+                                      torch.nn.Dropout(0.1), torch.nn.Linear(256, 128))
+    enc.forward = lambda x: enc.encoder(x)
+    cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+    model = sm.scMomer(cfg, atac_config=None, rna_decoder=None, atac_decoder=None, encoder=enc)
+    model.load_state_dict(p, strict=True)
+    model.eval()
+    cells = torch.from_numpy(O.synthetic_cells(seed, 2, 16906))
+    with torch.no_grad():
+        emb = model.get_cell_embedding(cells)
+        per_gene = model.rna_model(torch.round(cells).long().clamp(min=0, max=5))
+    fx = {"seed": np.int64(seed), "embedding": emb.numpy(), "per_gene_sample": per_gene.numpy()[:, ::97],
+          "per_gene_l2": np.float64(per_gene.double().norm().item())}
+    for kname, val in p.items():
+        if kname.endswith("projection_matrix"):
+            fx["param:" + kname] = val.numpy()
+    np.savez_compressed(os.path.join(out, "scmomer_embed.npz"), **fx)
+
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)))
 
