@@ -81,6 +81,11 @@ def cpu_baseline():
                       f"({dt:.1f} s)"}
 
 
+def _say(msg):
+    if os.environ.get("SCM_BENCH_VERBOSE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,12 +93,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the kernels have no CPU path")
+    # rehearsal switches (one-GPU boxes): SCM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, SCM_BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device.  Never set by the driver.
+    if os.environ.get("SCM_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("SCM_BENCH_BACKEND", "nccl"), init_method="env://",
+                                world_size=world, rank=rank)
 
+    _say("process group up")
     from scmomer_amd import dist as sdist
     from scmomer_amd import ops, s1, stack
     torch.manual_seed(2024 + rank)
@@ -161,9 +172,12 @@ def main():
         if (i + 1) % args.grad_acc == 0:
             sync_step()
 
+    _say("graph captured" if graph is not None else "eager mode")
     for i in range(args.warmup):
         step(i)
+        _say(f"warm-up step {i} issued")
     torch.cuda.synchronize()
+    _say("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -174,6 +188,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    _say("timed region done")
     dt = sdist.max_over_ranks(dt, device)
     final_loss = float(static_loss.item()) * args.grad_acc
 

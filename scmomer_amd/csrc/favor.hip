@@ -777,17 +777,23 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       f32x16 Yk[2] = {zero16(), zero16()};
       f32x16 Yv[2] = {zero16(), zero16()};
       float rs = 0.f;
-      auto tile = [&](int t, auto last_c) {
-        constexpr bool LAST = decltype(last_c)::value;
+      // Software pipeline over the 9 feature tiles: the score products of tile t+1 are issued before the vector
+      // work of tile t, so the matrix unit runs under the exponentials instead of waiting behind them.
+      // X[m,token] = Omega_t k^T ; G[m,token] = dC_t v^T
+      auto scores = [&](int t, f32x16& X, f32x16& G) {
         const char* ob_ = omg + t * 4096;
         const char* mb_ = mim + t * 4096;
-        f32x16 X = zero16(), G = zero16();
-        // X[m,token] = Omega_t k^T ; G[m,token] = dC_t v^T
+        X = zero16(); G = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           X = mfma32(*(const bf16x8*)(ob_ + lo.row[ks]), xf[ks], X);
           G = mfma32(*(const bf16x8*)(mb_ + lo.row[ks]), vf[ks], G);
         }
+      };
+      auto finish = [&](int t, const f32x16& X, const f32x16& G, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const char* ob_ = omg + t * 4096;
+        const char* mb_ = mim + t * 4096;
         f32x16 E, dA;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -814,9 +820,18 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           }
         }
       };
+      {
+        f32x16 X0, G0, X1, G1;
+        scores(0, X0, G0);
 #pragma unroll 1
-      for (int t = 0; t < NFT - 1; ++t) tile(t, std::false_type{});
-      tile(NFT - 1, std::true_type{});
+        for (int t = 0; t < NFT - 1; t += 2) {
+          scores(t + 1, X1, G1);
+          finish(t, X0, G0, std::false_type{});
+          scores(t + 2, X0, G0);
+          finish(t + 1, X1, G1, std::false_type{});
+        }
+        finish(NFT - 1, X0, G0, std::true_type{});
+      }
       const float ddiag = -xhalf_sum(rs);
       if (valid && l < 32) ksum -= ddiag;
       // dv = E dC + eps * colsum(dC)

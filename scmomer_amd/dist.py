@@ -79,7 +79,13 @@ class GradientAverager:
                 v.zero_()
             else:
                 v.copy_(p.grad)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # CPU-only backend (rehearsals on a box without RCCL peers): stage the bucket through host memory
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -100,6 +106,6 @@ def max_over_ranks(seconds: float, device) -> float:
     """Step time of the job = the slowest rank's."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
