@@ -720,11 +720,12 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           G = mfma32(*(const bf16x8*)(mb_ + lo.row[ks]), dof[ks], G);
         }
         f32x16 dA;
+        int jr = 64;   // row (without the 4*half part) of the first arg-max element of this tile, if any
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 3; g >= 0; --g) {
           const f32x4 z4 = *(const f32x4*)(zv + 32 * t + 8 * g + 4 * half);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 3; i >= 0; --i) {
             const int r = 4 * g + i;
             float e = exp2_fast(X[r] * (CNORM * LOG2E) - off);
             const bool fv = !LAST || acc_row(r, half) < NF - 32 * (NFT - 1);
@@ -733,14 +734,16 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
             rs += v;
             // The stabiliser routes -sum(dA) to the arg-max feature j*, so dA[j*] Omega[j*] cancels
             // against it exactly: keep that (largest) element out of the bf16 product and apply the
-            // net coefficient -(sum of the other dA) in f32 at the write-back.
+            // net coefficient -(sum of the other dA) in f32 at the write-back.  Rows are visited downwards,
+            // so the last assignment to jr is the smallest matching row.
             const bool ismax = fv && X[r] == rmx;
-            jstar = ismax ? min(jstar, 32 * t + acc_row(r, half)) : jstar;
+            jr = ismax ? acc_row(r, 0) : jr;
             const float vm = ismax ? 0.f : v;
             dA[r] = vm;
             rsm += vm;
           }
         }
+        jstar = (jr < 64 && jstar >= (1 << 20)) ? 32 * t + jr + 4 * half : jstar;
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk) {
           const bf16x8 af = acc_to_frag(dA, sk);
