@@ -81,6 +81,36 @@ def cpu_baseline():
                       f"({dt:.1f} s)"}
 
 
+# trace id -> kernel symbol as rocprofv3 lists it (for the counter-derived traffic of the dominant kernel)
+TRACE_SYMBOL = {"favor_apply_fwd": "favor_apply_kernel<0>", "favor_apply_bwd_q": "favor_apply_kernel<1>",
+                "favor_apply_bwd_k": "favor_apply_kernel<2>", "favor_ctx_fwd": "favor_ctx_kernel<0>",
+                "favor_ctx_bwd": "favor_ctx_kernel<1>", "wgrad": "wgrad_dma_kernel<false>",
+                "wgrad/bias": "wgrad_dma_kernel<true>", "gemm_nt/f32_bias_res": "gemm_nt_dma_kernel<1>",
+                "gemm_nt/f32": "gemm_nt_dma_kernel<4>", "gemm_skinny/bf16": "gemm_skinny_kernel<false, 0>",
+                "gemm_skinny/gelu_dual": "gemm_skinny_kernel<false, 2>", "gemm_skinny/dgelu": "gemm_skinny_kernel<false, 3>"}
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (profiles/rNN_pmc_fetch_write_
+    summary.txt: separate FETCH_SIZE and WRITE_SIZE passes of this same bench, mean per dispatch, in KB).  On gfx950
+    FETCH_SIZE counts wide coalesced reads at half their bytes, so it is doubled; WRITE_SIZE is exact.  None when no
+    summary covers the kernel."""
+    import glob
+    import re
+    sym = TRACE_SYMBOL.get(kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.txt")))
+    if not sym or not files:
+        return None, None
+    lines = open(files[-1]).read().splitlines()
+    for i, ln in enumerate(lines[:-1]):
+        if ln.strip() == sym:
+            f = re.search(r"FETCH_SIZE=([0-9.e+]+)", lines[i + 1])
+            w = re.search(r"WRITE_SIZE=([0-9.e+]+)", lines[i + 1])
+            if f and w:
+                return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.basename(files[-1])
+    return None, None
+
+
 def _say(msg):
     if os.environ.get("SCM_BENCH_VERBOSE") == "1":
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -214,12 +244,13 @@ def main():
         ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # FLOP per byte where the two roofs meet
         bound = "mfma" if by <= 0 or fl / by >= ridge else "hbm"
         tflops, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(dominant)
         roof = {"bound": bound, "kernel": dominant,
                 "achieved": tflops if bound == "mfma" else gbs,
                 "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                 "frac": tflops / PEAK_BF16_TFLOPS if bound == "mfma" else gbs / PEAK_HBM_GBS,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": ms / cnt, "launches_per_step": cnt / traced_steps,
                 "algorithmic_bytes_per_launch": by / cnt, "algorithmic_flops_per_launch": fl / cnt,
                 "tflops": tflops, "gbs": gbs, "share_of_kernel_time": ms / sum(v[0] for v in trace.values()),

@@ -11,7 +11,7 @@ timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f
 echo "fetch ok"
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/write.err || { echo "write pass failed"; tail -5 $OUT/write.err; exit 1; }
 echo "write ok"
-python tools/prof_summary.py $OUT/trace 28 40 > $OUT/kernel_stats_summary.txt
+python tools/prof_summary.py $OUT/trace 30 60 > $OUT/kernel_stats_summary.txt
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.txt
 # keep only the summaries and the stats csv (the raw traces are large)
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
