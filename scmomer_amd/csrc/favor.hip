@@ -30,10 +30,9 @@
 namespace scm {
 
 constexpr int STAGE_PITCH = 68;                     // floats per staged output row (64 + 4 spare)
-// favor_apply LDS: Omega and context images, z, sums, 8 output stages; then 8 x 1 KB of junk for the
-// prefetch-by-touch copies
+// favor_apply LDS: Omega and context images, z, sums, 8 output stages
 constexpr int APPLY_LDS_MAIN = 2 * NFP * 128 + (NFP + SUMS_STRIDE) * 4 + 8 * 32 * STAGE_PITCH * 4;
-constexpr int APPLY_LDS = APPLY_LDS_MAIN + 8 * 1024;
+constexpr int APPLY_LDS = APPLY_LDS_MAIN;
 
 SCM_DEV void load_image(char* img, const bf16* __restrict__ src /*[288][64]*/, int tid, int nthreads) {
   for (int c = tid; c < NFP * 8; c += nthreads) {
@@ -60,16 +59,6 @@ SCM_DEV void load_token_frags(bf16x8 (&f)[4], const bf16* __restrict__ row, bool
   const int half = lane_id() >> 5;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) f[ks] = valid ? *(const bf16x8*)(row + 16 * ks + 8 * half) : zero_frag();
-}
-
-// Touch the 128-byte rows of the 32 tokens that the NEXT iteration of this wave will load: an asynchronous
-// global->LDS copy of 16 bytes per lane (lane halves cover both 64-byte halves of a row) into a junk area that is
-// never read.  The lines are then in L2 when the real fragment loads arrive, which turns their HBM latency into an
-// L2 hit without staging registers.  `after` orders the copy behind the loads the current iteration has already
-// consumed: memory operations complete in issue order, so a copy issued before them would delay them.
-SCM_DEV void warm_rows(u32x4 rsrc, uint32_t junk_lds, uint32_t voffset, float after) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(junk_lds), "v"(voffset), "s"(rsrc), "v"(after) : "memory");
 }
 
 SCM_DEV float frag_sumsq(const bf16x8 (&f)[4]) {
@@ -546,40 +535,38 @@ SCM_DEV void stage_rows(float* stage, const f32x16 (&y)[2], float scale, const f
 // coalesced write-back of a staged [32][64] f32 tile as bf16; optional rank-1 correction
 // out[row][d] = stage[row][d] + stage[row][64] * corr_scale * xrow[d]
 // and, with omg != null, + stage[row][65] * Omega[(int)stage[row][66]][d] (Omega from its LDS image)
-SCM_DEV void store_rows(const float* stage, bf16* __restrict__ obase, long osn, const bf16* __restrict__ xbase,
-                        long xsn, float corr_scale, int n0, int n_hi, const char* omg = nullptr,
-                        const float* colbias = nullptr) {
+SCM_DEV void store_rows(const float* stage, brsrc ro, long osn, bool with_x, brsrc rxx, long xsn, float corr_scale,
+                        int n0, int n_hi, const char* omg = nullptr, const float* colbias = nullptr) {
   const int l = lane_id();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 8 * i + (l >> 3), ch = l & 7;
     const int n = n0 + row;
-    if (n < n_hi) {
-      const f32x4 a = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch);
-      const f32x4 b = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch + 4);
-      float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      if (colbias) {
+    const bool ok = n < n_hi;     // rows past the chunk: loads return 0, stores are dropped (no branches)
+    const f32x4 a = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch);
+    const f32x4 b = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (colbias) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += colbias[8 * ch + j];
-      }
-      if (xbase) {
-        const float cs = stage[row * STAGE_PITCH + 64] * corr_scale;
-        const bf16x8 xv = *(const bf16x8*)(xbase + (long)n * xsn + 8 * ch);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += cs * (float)xv[j];
-      }
-      if (omg) {
-        const float os = stage[row * STAGE_PITCH + 65];
-        const int jr = ((const int*)stage)[row * STAGE_PITCH + 66];
-        const bf16x8 ov = *(const bf16x8*)(omg + img_off(jr, 8 * ch));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += os * (float)ov[j];
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-      *(bf16x8*)(obase + (long)n * osn + 8 * ch) = o;
+      for (int j = 0; j < 8; ++j) v[j] += colbias[8 * ch + j];
     }
+    if (with_x) {
+      const float cs = stage[row * STAGE_PITCH + 64] * corr_scale;
+      const bf16x8 xv = as_bf16x8(buf_load16(rxx, ok ? (uint32_t)((long)n * xsn + 8 * ch) * 2 : BUF_OOB));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += cs * (float)xv[j];
+    }
+    if (omg) {
+      const float os = stage[row * STAGE_PITCH + 65];
+      const int jr = ((const int*)stage)[row * STAGE_PITCH + 66];
+      const bf16x8 ov = *(const bf16x8*)(omg + img_off(jr, 8 * ch));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += os * (float)ov[j];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+    buf_store16(ro, ok ? (uint32_t)((long)n * osn + 8 * ch) * 2 : BUF_OOB, as_u32x4(o));
   }
 }
 
@@ -609,30 +596,54 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
   const long srow = (long)bh * a.N;
   float ksum = 0.f;  // MODE 2: sum over this wave's tokens of sum_m dA
   const LaneOffs lo = lane_offs();
-  // prefetch-by-touch of the next tile's rows (see warm_rows): one resource per streamed tensor of this (b,h)
-  const uint32_t junk = lds_addr_of(smem) + (uint32_t)APPLY_LDS_MAIN + 1024 * __builtin_amdgcn_readfirstlane(w);
-  const u32x4 rx = dma_rsrc(xb, (uint32_t)(((long)(a.N - 1) * a.x.sn + DH) * 2));
+  // Every streamed tensor of this (b,h) goes through a bounds-checked buffer resource (rows past the chunk pass
+  // BUF_OOB: loads return 0, stores are dropped), so the loop body has no exec-mask branches around memory
+  // operations.  The fragments of the wave's NEXT tile are fetched right before the current tile's output is
+  // stored: memory operations complete in issue order, so loads issued after the stores would wait for them.
+  const brsrc rx = make_rsrc(xb, (uint32_t)(((long)(a.N - 1) * a.x.sn + DH) * 2));
   const bf16* yb_ = (MODE != 0) ? a.y.p + b * a.y.sb + h * a.y.sh : xb;
   const bf16* y2b_ = (MODE == 1) ? a.y2.p + b * a.y2.sb + h * a.y2.sh : xb;
-  const u32x4 ry = dma_rsrc(yb_, (uint32_t)(((long)(a.N - 1) * a.y.sn + DH) * 2));
-  const u32x4 ry2 = dma_rsrc(y2b_, (uint32_t)(((long)(a.N - 1) * a.y2.sn + DH) * 2));
-  auto warm_next = [&](int n, float after) {
-    const int nn = n + 256;
-    const bool nv = nn < n_hi;
-    warm_rows(rx, junk, nv ? (uint32_t)((long)nn * a.x.sn + 32 * half) * 2 : BUF_OOB, after);
-    if (MODE != 0) warm_rows(ry, junk, nv ? (uint32_t)((long)nn * a.y.sn + 32 * half) * 2 : BUF_OOB, after);
-    if (MODE == 1) warm_rows(ry2, junk, nv ? (uint32_t)((long)nn * a.y2.sn + 32 * half) * 2 : BUF_OOB, after);
+  const brsrc ry = make_rsrc(yb_, (uint32_t)(((long)(a.N - 1) * a.y.sn + DH) * 2));
+  const brsrc ry2 = make_rsrc(y2b_, (uint32_t)(((long)(a.N - 1) * a.y2.sn + DH) * 2));
+  const brsrc ro0 = make_rsrc(a.out0.p + b * a.out0.sb + h * a.out0.sh, (uint32_t)(((long)(a.N - 1) * a.out0.sn + DH) * 2));
+  const bf16* o1b_ = (MODE != 1) ? a.out1.p + b * a.out1.sb + h * a.out1.sh : xb;
+  const brsrc ro1 = make_rsrc(o1b_, (MODE != 1) ? (uint32_t)(((long)(a.N - 1) * a.out1.sn + DH) * 2) : 0u);
+  const brsrc rden = make_rsrc(MODE == 1 ? a.den_in + srow : nullptr, MODE == 1 ? (uint32_t)a.N * 4 : 0u);
+  const brsrc rstab = make_rsrc(MODE == 1 ? a.stab + srow : nullptr, MODE == 1 ? (uint32_t)a.N * 4 : 0u);
+  auto fetch = [&](int n0, bf16x8 (&fx)[4], bf16x8 (&fy)[4], bf16x8 (&fy2)[4], float& den, float& rmx) {
+    const int n = n0 + (l & 31);
+    const bool v = n < n_hi;
+    const uint32_t lane_off = (uint32_t)(8 * half) * 2;
+    const uint32_t bx = v ? (uint32_t)((long)n * a.x.sn) * 2 + lane_off : BUF_OOB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fx[ks] = as_bf16x8(buf_load16(rx, bx + 32 * ks));
+    if (MODE != 0) {
+      const uint32_t by = v ? (uint32_t)((long)n * a.y.sn) * 2 + lane_off : BUF_OOB;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fy[ks] = as_bf16x8(buf_load16(ry, by + 32 * ks));
+    }
+    if (MODE == 1) {
+      const uint32_t by2 = v ? (uint32_t)((long)n * a.y2.sn) * 2 + lane_off : BUF_OOB;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fy2[ks] = as_bf16x8(buf_load16(ry2, by2 + 32 * ks));
+      const uint32_t so = v ? (uint32_t)n * 4 : BUF_OOB;
+      const float d = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rden, (int)so, 0, 0));
+      den = v ? d : 1.f;
+      rmx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rstab, (int)so, 0, 0));
+    }
   };
 
+  bf16x8 xf[4], yf[4], y2f[4];
+  float den_c = 1.f, rmx_c = 0.f;
+  fetch(n_lo + 32 * w, xf, yf, y2f, den_c, rmx_c);
   for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 256) {
     const int n = n0 + (l & 31);
     const bool valid = n < n_hi;
-    bf16x8 xf[4];
-    load_token_frags(xf, xb + (long)n * a.x.sn, valid);
+    bf16x8 nxf[4], nyf[4], ny2f[4];   // the next tile's fragments, fetched before this tile's stores
+    float nden = 1.f, nrmx = 0.f;
     const float norm2 = frag_sumsq(xf);
 
     if (MODE == 0) {
-      warm_next(n, norm2);
       f32x16 X[NFT];
       float mx = -INFINITY;
 #pragma unroll
@@ -673,30 +684,26 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       const float inv = 1.f / den;
       // the context image is centred (its feature-sum is zero, so the eps term vanishes):
       // Y / den = o - obar
+      fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
       stage_rows(stage, Y, inv, nullptr, 0.f);
       __builtin_amdgcn_wave_barrier();
-      bf16* ocb = a.out1.p + b * a.out1.sb + h * a.out1.sh;
-      store_rows(stage, ocb, a.out1.sn, nullptr, 0, 0.f, n0, n_hi);
-      bf16* ob = a.out0.p + b * a.out0.sb + h * a.out0.sh;
-      store_rows(stage, ob, a.out0.sn, nullptr, 0, 0.f, n0, n_hi, nullptr, sm);
+      store_rows(stage, ro1, a.out1.sn, false, rx, 0, 0.f, n0, n_hi);
+      store_rows(stage, ro0, a.out0.sn, false, rx, 0, 0.f, n0, n_hi, nullptr, sm);
       __builtin_amdgcn_wave_barrier();
       if (valid && l < 32) { a.rowmax_out[srow + n] = mx; a.den_out[srow + n] = den; }
     }
 
     if (MODE == 1) {
-      const bf16* dob = a.y.p + b * a.y.sb + h * a.y.sh;
-      const bf16* ob = a.y2.p + b * a.y2.sb + h * a.y2.sh;
-      bf16x8 dof[4], of[4];
-      load_token_frags(dof, dob + (long)n * a.y.sn, valid);
-      load_token_frags(of, ob + (long)n * a.y2.sn, valid);
+      bf16x8 (&dof)[4] = yf;            // dO fragments (scaled by 1/den below), centred-output fragments
+      const bf16x8 (&of)[4] = y2f;
       float delta = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[ks][j];
       delta = xhalf_sum(delta);
-      const float den = valid ? a.den_in[srow + n] : 1.f;
-      const float rmx = valid ? a.stab[srow + n] : 0.f;
+      const float den = den_c;
+      const float rmx = rmx_c;
       const float inv = 1.f / den;
       const float dden = -delta * inv;
 #pragma unroll
@@ -704,7 +711,6 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) dof[ks][j] = (bf16)((float)dof[ks][j] * inv);
       const float off = (HALF_C2 * norm2 + CNORM * rmx) * LOG2E;
-      warm_next(n, off + dden);
       f32x16 Y[2] = {zero16(), zero16()};
       float rs = 0.f, rsm = 0.f;
       int jstar = 1 << 20;
@@ -757,6 +763,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       const float ddiag = -xhalf_sum(rs);
       const float stabc = -xhalf_sum(rsm);
       jstar = min(jstar, __shfl_xor(jstar, 32));
+      fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
       stage_rows(stage, Y, CNORM, nullptr, 0.f);
       if (l < 32) {
         stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
@@ -765,38 +772,28 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
         ((int*)stage)[(l & 31) * STAGE_PITCH + 66] = (jstar < NF) ? jstar : 0;
       }
       __builtin_amdgcn_wave_barrier();
-      bf16* dqb = a.out0.p + b * a.out0.sb + h * a.out0.sh;
-      store_rows(stage, dqb, a.out0.sn, xb, a.x.sn, 2.f * HALF_C2, n0, n_hi, omg);
+      store_rows(stage, ro0, a.out0.sn, true, rx, a.x.sn, 2.f * HALF_C2, n0, n_hi, omg);
       __builtin_amdgcn_wave_barrier();
       if (valid && l < 32) a.dden_out[srow + n] = dden;
     }
 
     if (MODE == 2) {
-      const bf16* vb = a.y.p + b * a.y.sb + h * a.y.sh;
-      bf16x8 vf[4];
-      load_token_frags(vf, vb + (long)n * a.y.sn, valid);
+      const bf16x8 (&vf)[4] = yf;
       const float off = (HALF_C2 * norm2 + CNORM * gstab) * LOG2E;
-      warm_next(n, off + (float)vf[3][7]);
       f32x16 Yk[2] = {zero16(), zero16()};
       f32x16 Yv[2] = {zero16(), zero16()};
       float rs = 0.f;
-      // Software pipeline over the 9 feature tiles: the score products of tile t+1 are issued before the vector
-      // work of tile t, so the matrix unit runs under the exponentials instead of waiting behind them.
-      // X[m,token] = Omega_t k^T ; G[m,token] = dC_t v^T
-      auto scores = [&](int t, f32x16& X, f32x16& G) {
+      auto tile = [&](int t, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         const char* ob_ = omg + t * 4096;
         const char* mb_ = mim + t * 4096;
-        X = zero16(); G = zero16();
+        f32x16 X = zero16(), G = zero16();
+        // X[m,token] = Omega_t k^T ; G[m,token] = dC_t v^T
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           X = mfma32(*(const bf16x8*)(ob_ + lo.row[ks]), xf[ks], X);
           G = mfma32(*(const bf16x8*)(mb_ + lo.row[ks]), vf[ks], G);
         }
-      };
-      auto finish = [&](int t, const f32x16& X, const f32x16& G, auto last_c) {
-        constexpr bool LAST = decltype(last_c)::value;
-        const char* ob_ = omg + t * 4096;
-        const char* mb_ = mim + t * 4096;
         f32x16 E, dA;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -823,33 +820,27 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           }
         }
       };
-      {
-        f32x16 X0, G0, X1, G1;
-        scores(0, X0, G0);
 #pragma unroll 1
-        for (int t = 0; t < NFT - 1; t += 2) {
-          scores(t + 1, X1, G1);
-          finish(t, X0, G0, std::false_type{});
-          scores(t + 2, X0, G0);
-          finish(t + 1, X1, G1, std::false_type{});
-        }
-        finish(NFT - 1, X0, G0, std::true_type{});
-      }
+      for (int t = 0; t < NFT - 1; ++t) tile(t, std::false_type{});
+      tile(NFT - 1, std::true_type{});
       const float ddiag = -xhalf_sum(rs);
       if (valid && l < 32) ksum -= ddiag;
+      fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
       // dv = E dC + eps * colsum(dC)
       stage_rows(stage, Yv, 1.f, sm, KEPS);
       __builtin_amdgcn_wave_barrier();
-      bf16* dvb = a.out1.p + b * a.out1.sb + h * a.out1.sh;
-      store_rows(stage, dvb, a.out1.sn, nullptr, 0, 0.f, n0, n_hi);
+      store_rows(stage, ro1, a.out1.sn, false, rx, 0, 0.f, n0, n_hi);
       __builtin_amdgcn_wave_barrier();
       stage_rows(stage, Yk, CNORM, nullptr, 0.f);
       if (l < 32) stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
       __builtin_amdgcn_wave_barrier();
-      bf16* dkb = a.out0.p + b * a.out0.sb + h * a.out0.sh;
-      store_rows(stage, dkb, a.out0.sn, xb, a.x.sn, 2.f * HALF_C2, n0, n_hi);
+      store_rows(stage, ro0, a.out0.sn, true, rx, a.x.sn, 2.f * HALF_C2, n0, n_hi);
       __builtin_amdgcn_wave_barrier();
     }
+    // rotate: the prefetched fragments become the current ones
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { xf[ks] = nxf[ks]; if (MODE != 0) yf[ks] = nyf[ks]; if (MODE == 1) y2f[ks] = ny2f[ks]; }
+    den_c = nden; rmx_c = nrmx;
   }
   if (MODE == 2) {
     // fixed-order sum of the 8 wave totals -> one partial per workgroup
