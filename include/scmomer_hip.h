@@ -147,6 +147,28 @@ int scm_ce_fwd(const float* logits, const int64_t* labels, int64_t T, int C, int
 int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, const float* dloss,
                const float* loss_count, float* dlogits, void* stream);
 
+/* ---- data ingest: SCDataset.__getitem__ (s1_pretrain_rna.py:133-137: data[index].toarray()[0], values above
+ *      class_limit-2 set to it, .long()) and the scMomer rule (scmomer.py:56,108: round().long().clamp(0,5)) -----
+ * The expression matrix is CSR in device memory (indptr int64 [n_rows+1], indices int32, values f32; duplicate
+ * column indices of a row add up).  Cell b of the batch is row rows[b] (rows == NULL: row b).  tokens int64 [B,N].
+ * rule 0: v > limit -> limit, then truncation toward zero; rule 1: round half to even, clamp to [0, limit].
+ * *err_flag (device int, caller zeroes it) gets bit 0 for a row index outside [0,n_rows) and bit 1 for a column
+ * index outside [0,N); such entries are skipped.  N <= scm_bin_max_genes() (the dense row is built in LDS). */
+int scm_bin_max_genes(void);
+int scm_bin_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows,
+                int64_t n_rows, int B, int N, int rule, int limit, int64_t* tokens, int* err_flag, void* stream);
+/* The same two rules on dense f32 values [total]. */
+int scm_bin_dense(const float* x, int64_t total, int rule, int limit, int64_t* tokens, void* stream);
+
+/* ---- projection redraw: gaussian_orthogonal_random_matrix + orthogonal_matrix_chunk
+ *      (performer_pytorch.py:110-139) for nmat matrices at once, from Gaussian draws the caller made --------------
+ * gauss_blocks f32 [nmat, ceil(nb_rows/64), 64, 64]: the unstructured blocks; each is QR-factorised (Householder,
+ * LAPACK conventions) and contributes the rows of Q^T (the last block only nb_rows % 64 of them).
+ * scaling 0: row r is multiplied by the 2-norm of gauss_mult[m, r, :] (f32 [nmat, nb_rows, 64]); scaling 1: by 8.
+ * omega f32 [nmat, nb_rows, 64]. */
+int scm_orthogonal_omega(const float* gauss_blocks, const float* gauss_mult, int nmat, int nb_rows, int scaling,
+                         float* omega, void* stream);
+
 /* ---- measurement aid (no reference counterpart): per-kernel durations from HIP events recorded on the
  *      launch stream around each launch of the selected kernel.  scm_trace_enable(kid): -1 off,
  *      scm_trace_kernel_count() = every kernel, else one kernel id.  scm_trace_collect waits for the recorded

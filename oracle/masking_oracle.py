@@ -28,6 +28,23 @@ def bin_scmomer(x: np.ndarray) -> np.ndarray:
     return np.clip(np.rint(np.asarray(x, dtype=np.float32)).astype(np.int64), 0, 5)
 
 
+def csr_rows_to_tokens(indptr, indices, values, rows, n_genes: int, rule: int, limit: int = 5) -> np.ndarray:
+    """Sparse rows -> dense float32 rows (duplicate column entries add up, as scipy's ``toarray()`` of
+    s1_pretrain_rna.py:134 does) -> tokens.  rule 0: the S1 rule (:135-136) with ``limit = class_limit - 2``;
+    rule 1: the scMomer rule (scmomer.py:56,108) with clamp to [0, limit]."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    out = np.zeros((len(rows), n_genes), dtype=np.int64)
+    for b, r in enumerate(rows):
+        dense = np.zeros(n_genes, dtype=np.float32)
+        lo, hi = int(indptr[r]), int(indptr[r + 1])
+        np.add.at(dense, np.asarray(indices[lo:hi], dtype=np.int64), np.asarray(values[lo:hi], dtype=np.float32))
+        if rule == 0:
+            out[b] = bin_s1(dense, limit + 2)
+        else:
+            out[b] = np.clip(np.rint(dense).astype(np.int64), 0, limit)
+    return out
+
+
 def mask_subset_with_prob(maskable: np.ndarray, prob: float, rand_pick: np.ndarray) -> np.ndarray:
     """get_mask_subset_with_prob, s1_pretrain_rna.py:98-110.
 

@@ -52,6 +52,10 @@ SIGNATURES = {
                                 C.POINTER(C.c_int64)]),
     "scm_s1_mask": (i32, [vp, vp, vp, i32, i32, C.c_float, C.c_float, i32, i64, i64, vp, vp, vp]),
     "scm_ce_ws_floats": (i64, [i64]),
+    "scm_bin_max_genes": (i32, []),
+    "scm_bin_csr": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]),
+    "scm_bin_dense": (i32, [vp, i64, i32, i32, vp, vp]),
+    "scm_orthogonal_omega": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "scm_ce_fwd": (i32, [vp, vp, i64, i32, i64, vp, vp, vp]),
     "scm_ce_bwd": (i32, [vp, vp, i64, i32, i64, vp, vp, vp, vp]),
     "scm_head_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -48,7 +48,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -313,6 +313,39 @@ int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int
   SCM_REQ(logits && labels && dloss && loss_count && dlogits, "scm_ce_bwd: null pointer");
   SCM_REQ(T > 0 && C > 0 && C <= 8, "scm_ce_bwd: need 1 <= C <= 8");
   SCM_HIP(ce_bwd(logits, labels, T, C, ignore_index, dloss, loss_count, dlogits, (hipStream_t)stream), "scm_ce_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- ingest and projection redraw
+int scm_bin_max_genes(void) { return BIN_MAX_GENES; }
+
+int scm_bin_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows,
+                int64_t n_rows, int B, int N, int rule, int limit, int64_t* tokens, int* err_flag, void* stream) {
+  SCM_REQ(indptr && indices && values && tokens && err_flag, "scm_bin_csr: null pointer");
+  SCM_REQ(B > 0 && N > 0 && N <= BIN_MAX_GENES && n_rows > 0 && n_rows < (1ll << 31),
+          "scm_bin_csr: need 0 < N <= scm_bin_max_genes() and 0 < n_rows < 2^31");
+  SCM_REQ((rule == 0 || rule == 1) && limit >= 0 && limit < (1 << 24), "scm_bin_csr: rule is 0 (S1) or 1 (scMomer)");
+  SCM_REQ(rows || B <= n_rows, "scm_bin_csr: without a row list B must not exceed n_rows");
+  SCM_HIP(bin_csr(indptr, indices, values, rows, (int)n_rows, B, N, rule, limit, tokens, err_flag, (hipStream_t)stream),
+          "scm_bin_csr");
+  return 0;
+}
+
+int scm_bin_dense(const float* x, int64_t total, int rule, int limit, int64_t* tokens, void* stream) {
+  SCM_REQ(x && tokens, "scm_bin_dense: null pointer");
+  SCM_REQ(total > 0, "scm_bin_dense: empty input");
+  SCM_REQ((rule == 0 || rule == 1) && limit >= 0 && limit < (1 << 24), "scm_bin_dense: rule is 0 (S1) or 1 (scMomer)");
+  SCM_HIP(bin_dense(x, total, rule, limit, tokens, (hipStream_t)stream), "scm_bin_dense");
+  return 0;
+}
+
+int scm_orthogonal_omega(const float* gauss_blocks, const float* gauss_mult, int nmat, int nb_rows, int scaling,
+                         float* omega, void* stream) {
+  SCM_REQ(gauss_blocks && omega && (gauss_mult || scaling == 1), "scm_orthogonal_omega: null pointer");
+  SCM_REQ(nmat > 0 && nmat <= 65535 && nb_rows > 0 && nb_rows <= 64 * 1024, "scm_orthogonal_omega: bad sizes");
+  SCM_REQ(scaling == 0 || scaling == 1, "scm_orthogonal_omega: scaling is 0 or 1");
+  SCM_HIP(orthogonal_omega(gauss_blocks, gauss_mult, nmat, nb_rows, scaling, omega, (hipStream_t)stream),
+          "scm_orthogonal_omega");
   return 0;
 }
 

@@ -62,7 +62,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_GEMM_SKINNY = 6,        // gemm_skinny_kernel, + epilogue id (6 consecutive ids)
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
-  K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_COUNT
+  K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_BIN, K_OMEGA_QR, K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
@@ -113,6 +113,14 @@ hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, lon
                   float* out, hipStream_t s);
 hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, const float* dloss,
                   const float* loss_count, float* dlogits, hipStream_t s);
+
+// ingest.hip
+constexpr int BIN_MAX_GENES = 36864;   // dense f32 row of one cell in LDS (144 KB)
+hipError_t bin_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows, int n_rows,
+                   int B, int N, int rule, int limit, int64_t* tokens, int* err, hipStream_t s);
+hipError_t bin_dense(const float* x, long total, int rule, int limit, int64_t* tokens, hipStream_t s);
+hipError_t orthogonal_omega(const float* gauss_blocks, const float* gauss_mult, int nmat, int nb_rows, int scaling,
+                            float* omega, hipStream_t s);
 
 // favor.hip
 hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s);

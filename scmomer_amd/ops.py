@@ -286,6 +286,57 @@ def ce_bwd(logits, labels, ignore_index: int, dloss: torch.Tensor, loss_count: t
     return dlogits
 
 
+# ----------------------------------------------------------------------------- ingest, projection redraw
+RULE_S1, RULE_SCMOMER = 0, 1
+
+
+def bin_csr(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor, rows: Optional[torch.Tensor],
+            n_genes: int, rule: int, limit: int, err_flag: torch.Tensor, batch: Optional[int] = None) -> torch.Tensor:
+    """CSR rows (device resident) -> binned int64 tokens [B, n_genes]; rows: int64 [B] row numbers or None for
+    rows 0..batch-1.  err_flag: device int32 scalar the caller owns (bits are OR-ed in, never cleared here)."""
+    _req(indptr, torch.int64, "indptr")
+    _req(indices, torch.int32, "indices")
+    _req(values, F32, "values")
+    _req(err_flag, torch.int32, "err_flag")
+    if rows is not None:
+        _req(rows, torch.int64, "rows")
+        batch = rows.numel()
+    n_rows = indptr.numel() - 1
+    tokens = torch.empty((batch, n_genes), dtype=torch.int64, device=values.device)
+    if batch == 0:
+        return tokens
+    check(lib.scm_bin_csr(_p(indptr), _p(indices), _p(values), _p(rows), n_rows, batch, n_genes, rule, limit,
+                          _p(tokens), _p(err_flag), _stream()), "scm_bin_csr")
+    return tokens
+
+
+def bin_dense(x: torch.Tensor, rule: int, limit: int) -> torch.Tensor:
+    _req(x, F32, "x")
+    tokens = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    if x.numel():
+        check(lib.scm_bin_dense(_p(x), x.numel(), rule, limit, _p(tokens), _stream()), "scm_bin_dense")
+    return tokens
+
+
+def orthogonal_omega(gauss_blocks: torch.Tensor, gauss_mult: Optional[torch.Tensor], nb_rows: int,
+                     scaling: int = 0) -> torch.Tensor:
+    """gauss_blocks f32 [nmat, ceil(nb_rows/64), 64, 64] (+ gauss_mult f32 [nmat, nb_rows, 64] for scaling 0)
+    -> projection matrices f32 [nmat, nb_rows, 64]."""
+    _req(gauss_blocks, F32, "gauss_blocks")
+    nmat = gauss_blocks.shape[0]
+    nblk = (nb_rows + DIM_HEAD - 1) // DIM_HEAD
+    if tuple(gauss_blocks.shape) != (nmat, nblk, DIM_HEAD, DIM_HEAD):
+        raise ValueError(f"gauss_blocks: expected [{nmat},{nblk},64,64], got {tuple(gauss_blocks.shape)}")
+    if scaling == 0:
+        _req(gauss_mult, F32, "gauss_mult")
+        if tuple(gauss_mult.shape) != (nmat, nb_rows, DIM_HEAD):
+            raise ValueError(f"gauss_mult: expected [{nmat},{nb_rows},64], got {tuple(gauss_mult.shape)}")
+    omega = torch.empty((nmat, nb_rows, DIM_HEAD), dtype=F32, device=gauss_blocks.device)
+    check(lib.scm_orthogonal_omega(_p(gauss_blocks), _p(gauss_mult) if scaling == 0 else None, nmat, nb_rows, scaling,
+                                   _p(omega), _stream()), "scm_orthogonal_omega")
+    return omega
+
+
 # ----------------------------------------------------------------------------- per-kernel timing
 def trace_kernel_names():
     return [lib.scm_trace_kernel_name(i).decode() for i in range(lib.scm_trace_kernel_count())]

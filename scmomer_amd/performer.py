@@ -77,7 +77,26 @@ def orthogonal_matrix_chunk(cols, device=None):
     return q.to(device).t()
 
 
+def _on_gpu(device) -> bool:
+    return device is not None and torch.device(device).type == "cuda"
+
+
+def _projection_draws(nb_rows, nb_columns, scaling, device):
+    """The Gaussian draws of one projection matrix, in the reference's order (performer_pytorch.py:119-133): one
+    [cols, cols] block per 64 rows (the last one partly used), then the [rows, cols] matrix of the row norms."""
+    nblk = (nb_rows + nb_columns - 1) // nb_columns
+    blocks = torch.stack([torch.randn((nb_columns, nb_columns), device=device) for _ in range(nblk)])
+    mult = torch.randn((nb_rows, nb_columns), device=device) if scaling == 0 else None
+    return blocks, mult
+
+
 def gaussian_orthogonal_random_matrix(nb_rows, nb_columns, scaling=0, device=None):
+    if scaling not in (0, 1):
+        raise ValueError(f"Invalid scaling {scaling}")
+    if _on_gpu(device) and nb_columns == ops.DIM_HEAD:
+        # draws and the QR both happen on the device: no host round trip, no stall of the training stream
+        blocks, mult = _projection_draws(nb_rows, nb_columns, scaling, device)
+        return ops.orthogonal_omega(blocks[None], None if mult is None else mult[None], nb_rows, scaling)[0]
     nb_full_blocks = int(nb_rows / nb_columns)
     block_list = [orthogonal_matrix_chunk(nb_columns, device=device) for _ in range(nb_full_blocks)]
     remaining_rows = nb_rows - nb_full_blocks * nb_columns
@@ -86,11 +105,30 @@ def gaussian_orthogonal_random_matrix(nb_rows, nb_columns, scaling=0, device=Non
     final_matrix = torch.cat(block_list)
     if scaling == 0:
         multiplier = torch.randn((nb_rows, nb_columns), device=device).norm(dim=1)
-    elif scaling == 1:
-        multiplier = math.sqrt(float(nb_columns)) * torch.ones((nb_rows,), device=device)
     else:
-        raise ValueError(f"Invalid scaling {scaling}")
+        multiplier = math.sqrt(float(nb_columns)) * torch.ones((nb_rows,), device=device)
     return torch.diag(multiplier) @ final_matrix
+
+
+@torch.no_grad()
+def redraw_projection_matrices(fast_attentions, device) -> None:
+    """New projection matrices for a list of FastAttention modules with ONE kernel launch (the reference redraws
+    them one by one with a host QR each, performer_pytorch.py:527-531); the draws keep the per-module order."""
+    fast_attentions = list(fast_attentions)
+    if not fast_attentions:
+        return
+    same = len({(fa.nb_features, fa.dim_heads, fa.ortho_scaling) for fa in fast_attentions}) == 1
+    if not (_on_gpu(device) and same and fast_attentions[0].dim_heads == ops.DIM_HEAD):
+        for fa in fast_attentions:
+            fa.redraw_projection_matrix(device)
+        return
+    fa0 = fast_attentions[0]
+    draws = [_projection_draws(fa0.nb_features, fa0.dim_heads, fa0.ortho_scaling, device) for _ in fast_attentions]
+    blocks = torch.stack([d[0] for d in draws])
+    mult = torch.stack([d[1] for d in draws]) if fa0.ortho_scaling == 0 else None
+    omega = ops.orthogonal_omega(blocks, mult, fa0.nb_features, fa0.ortho_scaling)
+    for fa, om in zip(fast_attentions, omega):
+        fa.projection_matrix.copy_(om)
 
 
 # --------------------------------------------------------------------------------------------
@@ -314,22 +352,37 @@ class Performer(nn.Module):
         self.auto_check_redraw = auto_check_redraw
         self.feature_redraw_interval = feature_redraw_interval
         self.register_buffer("calls_since_last_redraw", torch.tensor(0))
+        self._calls_host = None
 
     def fix_projection_matrices_(self):
         self.feature_redraw_interval = None
 
+    def _calls(self) -> int:
+        """Host mirror of the calls_since_last_redraw buffer: the reference compares the device buffer on every
+        forward (a synchronisation per call); here the buffer is read once and then tracked on the host."""
+        if self._calls_host is None:
+            self._calls_host = int(self.calls_since_last_redraw.item())
+        return self._calls_host
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._calls_host = None
+
     def check_redraw_projections(self):
         """performer_pytorch.py:520-534: in train() mode, redraw every FastAttention projection after
-        feature_redraw_interval forward calls (host-side QR), else tick the counter."""
+        feature_redraw_interval forward calls, else tick the counter.  All matrices are redrawn by one device
+        kernel (draws and QR on the GPU), so the training stream does not wait for the host."""
         if not self.training:
             return
-        if exists(self.feature_redraw_interval) and self.calls_since_last_redraw >= self.feature_redraw_interval:
+        if exists(self.feature_redraw_interval) and self._calls() >= self.feature_redraw_interval:
             device = get_module_device(self)
-            for fast_attention in find_modules(self, FastAttention):
-                fast_attention.redraw_projection_matrix(device)
+            redraw_projection_matrices(find_modules(self, FastAttention), device)
             self.calls_since_last_redraw.zero_()
+            self._calls_host = 0
             return
         self.calls_since_last_redraw += 1
+        if self._calls_host is not None:
+            self._calls_host += 1
 
     def forward(self, x, output_attentions=False, **kwargs):
         _unsupported("output_attentions", output_attentions, False)

@@ -138,3 +138,26 @@ def test_scmomer_cell_embedding(golden_dir):
     with torch.no_grad():
         emb = O.scmomer_cell_embedding(cells, p)
     np.testing.assert_allclose(emb.numpy(), g["embedding"], rtol=2e-4, atol=2e-5)
+
+
+def test_householder_projection_matches_reference(golden_dir):
+    """The oracle's own Householder QR (the restatement the device kernel is checked against) reproduces the
+    reference's projection matrix from the same Gaussian draws: LAPACK float32 against numpy float64."""
+    g = load(golden_dir, "projection.npz")
+    torch.manual_seed(int(g["seed"]))
+    blocks = torch.stack([torch.randn(64, 64) for _ in range(5)]).numpy()   # the reference's draw order
+    mult = torch.randn(266, 64).numpy()
+    mine = O.omega_from_draws(blocks, mult, 266)
+    np.testing.assert_allclose(mine, g["proj"], rtol=0, atol=1e-4)
+    q = O.householder_q(blocks[0])
+    np.testing.assert_allclose(q @ q.T, np.eye(64), atol=1e-12)
+
+
+def test_csr_binning_matches_reference_bins(golden_dir):
+    """Sparse rows through the oracle's densify-and-bin restatement give the reference's tokens (both rules)."""
+    import scipy.sparse as sp
+    g = load(golden_dir, "mask_bin.npz")
+    m = sp.csr_matrix(g["cells"])
+    rows = list(range(m.shape[0]))
+    assert np.array_equal(MO.csr_rows_to_tokens(m.indptr, m.indices, m.data, rows, m.shape[1], 0), g["s1_bins"])
+    assert np.array_equal(MO.csr_rows_to_tokens(m.indptr, m.indices, m.data, rows, m.shape[1], 1), g["scmomer_bins"])
