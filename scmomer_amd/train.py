@@ -1,0 +1,423 @@
+"""The S1 RNA masked-autoencoding pretraining loop (s1_pretrain_rna.py:146-387) as a reusable driver: same step
+semantics (mask -> forward -> CE / grad_acc -> backward; every grad_acc-th micro-step: gradient average over the
+ranks, clip to norm 100, Adam, zero), same learning-rate schedule (utils.py:59-145), same accuracy definition,
+same checkpoint dictionary (``module.``-prefixed weights, optimizer and scheduler state, epoch, loss), same
+early stopping.  What differs is how it runs: masking, loss and encoder are device kernels, gradient accumulation
+is one multi-tensor add into static buffers, the data-parallel exchange is one flat all-reduce per optimizer step
+(dist.GradientAverager) instead of DDP's bucketed hooks, nothing synchronises with the host inside an epoch (the
+reference calls ``.item()`` twice per micro-step, :307,312), and the micro-step can be replayed from a HIP graph.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch.optim.lr_scheduler import LRScheduler
+
+from . import dist as sdist
+from . import s1
+
+PREFIX = "module."
+
+
+# ------------------------------------------------------------------------------------------------
+# learning-rate schedule
+# ------------------------------------------------------------------------------------------------
+class CosineAnnealingWarmupRestarts(LRScheduler):
+    """utils.py:59-145.  Cycles of ``cur_cycle_steps`` scheduler steps: linear warm-up from ``min_lr`` to the
+    cycle's ``max_lr`` over ``warmup_steps``, then half a cosine back down to ``min_lr``; each new cycle is
+    ``cycle_mult`` times longer (warm-up excluded) and its peak ``gamma`` times lower.  Attribute names are the
+    reference's, so its ``scheduler_state_dict`` loads here and the other way round.  As in the reference the
+    optimizer runs at ``min_lr`` until the first ``step()``."""
+
+    def __init__(self, optimizer: torch.optim.Optimizer, first_cycle_steps: int, cycle_mult: float = 1.,
+                 max_lr: float = 0.1, min_lr: float = 0.001, warmup_steps: int = 0, gamma: float = 1.,
+                 last_epoch: int = -1):
+        assert warmup_steps < first_cycle_steps
+        self.first_cycle_steps = first_cycle_steps
+        self.cycle_mult = cycle_mult
+        self.base_max_lr = max_lr
+        self.max_lr = max_lr
+        self.min_lr = min_lr
+        self.warmup_steps = warmup_steps
+        self.gamma = gamma
+        self.cur_cycle_steps = first_cycle_steps
+        self.cycle = 0
+        self.step_in_cycle = last_epoch
+        super().__init__(optimizer, last_epoch)
+        self.init_lr()
+
+    def init_lr(self):
+        self.base_lrs = [self.min_lr for _ in self.optimizer.param_groups]
+        for group in self.optimizer.param_groups:
+            group["lr"] = self.min_lr
+
+    def _lr_from(self, floor: float) -> float:
+        pos = self.step_in_cycle
+        if pos == -1:
+            return floor
+        span = self.max_lr - floor
+        if pos < self.warmup_steps:
+            return span * pos / self.warmup_steps + floor
+        phase = math.pi * (pos - self.warmup_steps) / (self.cur_cycle_steps - self.warmup_steps)
+        return floor + span * (1 + math.cos(phase)) / 2
+
+    def get_lr(self):
+        return [self._lr_from(floor) for floor in self.base_lrs]
+
+    def _advance_one(self):
+        self.step_in_cycle += 1
+        if self.step_in_cycle >= self.cur_cycle_steps:          # next cycle: longer by cycle_mult (warm-up excluded)
+            self.cycle += 1
+            self.step_in_cycle -= self.cur_cycle_steps
+            self.cur_cycle_steps = int((self.cur_cycle_steps - self.warmup_steps) * self.cycle_mult) + self.warmup_steps
+
+    def _jump_to(self, epoch):
+        first, mult = self.first_cycle_steps, self.cycle_mult
+        if epoch < first:
+            self.cur_cycle_steps, self.step_in_cycle = first, epoch
+        elif mult == 1.:
+            self.cycle, self.step_in_cycle = epoch // first, epoch % first
+        else:                                                   # geometric series of cycle lengths
+            n = int(math.log(epoch / first * (mult - 1) + 1, mult))
+            self.cycle = n
+            self.step_in_cycle = epoch - int(first * (mult ** n - 1) / (mult - 1))
+            self.cur_cycle_steps = first * mult ** n
+
+    def step(self, epoch=None):
+        if epoch is None:
+            epoch = self.last_epoch + 1
+            self._advance_one()
+        else:
+            self._jump_to(epoch)
+        self.max_lr = self.base_max_lr * (self.gamma ** self.cycle)
+        self.last_epoch = math.floor(epoch)
+        lrs = self.get_lr()
+        for group, lr in zip(self.optimizer.param_groups, lrs):
+            group["lr"] = lr
+        self._last_lr = lrs
+
+
+# ------------------------------------------------------------------------------------------------
+# pieces of the loop
+# ------------------------------------------------------------------------------------------------
+def s1_predictions(logits: torch.Tensor) -> torch.Tensor:
+    """s1_pretrain_rna.py:308-309: arg-max over the classes 1..C-2 (softmax is monotonic, so the logits do)."""
+    return logits[..., 1:-1].argmax(dim=-1) + 1
+
+
+def s1_batch_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int) -> torch.Tensor:
+    """s1_pretrain_rna.py:308-312: per cell, correct / predicted over the masked positions; mean over the cells
+    (a cell without masked positions yields nan, as in the reference).  Device scalar."""
+    final = s1_predictions(logits)
+    counted = labels != pad_id
+    pred_num = counted.sum(dim=-1)
+    correct_num = (counted * (final == labels)).sum(dim=-1)
+    return torch.true_divide(correct_num, pred_num).mean()
+
+
+def freeze_for_finetune(model) -> Tuple[int, int]:
+    """Finetune mode of s1_pretrain_rna.py:223-228: everything frozen except the final norm and the last two
+    Performer layers.  -> (total, trainable) parameter counts."""
+    for p in model.parameters():
+        p.requires_grad = False
+    for p in model.norm.parameters():
+        p.requires_grad = True
+    for p in model.performer.net.layers[-2:].parameters():
+        p.requires_grad = True
+    total = sum(p.numel() for p in model.parameters())
+    return total, sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def _strip_prefix(sd: Dict[str, torch.Tensor], prefix: str = PREFIX) -> Dict[str, torch.Tensor]:
+    if sd and all(k.startswith(prefix) for k in sd):
+        return {k[len(prefix):]: v for k, v in sd.items()}
+    return dict(sd)
+
+
+def checkpoint_dict(epoch: int, model, optimizer, scheduler, val_loss: float) -> dict:
+    """The dictionary of s1_pretrain_rna.py:370-376.  The reference saves the DDP wrapper's state_dict, whose keys
+    carry a ``module.`` prefix; the same keys are written here so that downstream loaders (the S2 script strips
+    the prefix) see the layout they expect."""
+    return {"epoch": epoch,
+            "model_state_dict": {PREFIX + k: v for k, v in model.state_dict().items()},
+            "optimizer_state_dict": optimizer.state_dict(),
+            "scheduler_state_dict": scheduler.state_dict(),
+            "losses": val_loss}
+
+
+def save_checkpoint(path: str, epoch: int, model, optimizer, scheduler, val_loss: float) -> None:
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(checkpoint_dict(epoch, model, optimizer, scheduler, val_loss), path)
+
+
+def load_checkpoint(path_or_dict, model, optimizer=None, scheduler=None) -> int:
+    """Resume (s1_pretrain_rna.py:207-215,258-266): weights (with or without the ``module.`` prefix), then the
+    optimizer and scheduler states when present and wanted.  -> the epoch to start with."""
+    ckpt = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu",
+                                                                         weights_only=True)
+    model.load_state_dict(_strip_prefix(ckpt["model_state_dict"]))
+    if optimizer is not None and "optimizer_state_dict" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    if scheduler is not None and "scheduler_state_dict" in ckpt:
+        scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+    return ckpt.get("epoch", 0) + 1
+
+
+def _device_mask(data, mask_prob, replace_prob, pad_id, mask_id):
+    return s1.data_mask_device(data, mask_prob, replace_prob, pad_id, mask_id)
+
+
+def _device_loss(logits, labels, pad_id):
+    return s1.masked_cross_entropy(logits, labels, pad_id)
+
+
+# ------------------------------------------------------------------------------------------------
+# the driver
+# ------------------------------------------------------------------------------------------------
+class S1Trainer:
+    """Owns optimizer, schedule, gradient accumulators and the data-parallel exchange for one model replica.
+
+    ``mask_fn(data, mask_prob, replace_prob, pad_id, mask_id) -> (masked_input, labels)`` and
+    ``loss_fn(logits, labels, pad_id) -> scalar`` default to the device kernels (there is no CPU path behind
+    them); host tests inject torch formulations to drive the bookkeeping without a GPU."""
+
+    def __init__(self, model, *, learning_rate: float = 1e-4, grad_acc: int = 20, mask_prob: float = 0.15,
+                 replace_prob: float = 0.9, bin_num: int = 5, max_grad_norm: float = int(1e2),
+                 group: Optional[dist.ProcessGroup] = None, use_graph: bool = False,
+                 mask_fn: Optional[Callable] = None, loss_fn: Optional[Callable] = None):
+        self.model = model
+        self.grad_acc = int(grad_acc)
+        self.mask_prob, self.replace_prob = mask_prob, replace_prob
+        self.num_classes = bin_num + 2                       # s1_pretrain_rna.py:154-156
+        self.pad_id = self.mask_id = self.num_classes - 1
+        self.max_grad_norm = max_grad_norm
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.mask_fn = mask_fn or _device_mask
+        self.loss_fn = loss_fn or _device_loss
+        # the reference hands ALL parameters to Adam (frozen ones never get a gradient and are skipped), which
+        # fixes the parameter numbering inside optimizer_state_dict
+        self.optimizer = torch.optim.Adam(list(model.parameters()), lr=learning_rate)
+        self.scheduler = CosineAnnealingWarmupRestarts(self.optimizer, first_cycle_steps=15, cycle_mult=2,
+                                                       max_lr=learning_rate, min_lr=1e-6, warmup_steps=5, gamma=0.9)
+        self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
+        self.accs = [torch.zeros_like(p) for p in self.params]
+        self.averager = sdist.GradientAverager(self.params, group) if self.params else None
+        sdist.broadcast_parameters(list(model.parameters()) + list(model.buffers()), src=0, group=group)
+        self.index = 0                                       # micro-steps since the start of the epoch
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_shape = None
+
+    # ---- one micro-step ---------------------------------------------------------------------
+    def _forward_backward(self, data: torch.Tensor):
+        masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
+        logits = self.model(masked)
+        loss = self.loss_fn(logits, labels, self.pad_id) / self.grad_acc
+        loss.backward()
+        torch._foreach_add_(self.accs, [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params])
+        for p in self.params:
+            p.grad = None                                    # the next backward stores, it does not add
+        return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
+
+    def _optimizer_step(self):
+        """The sync micro-step's tail (s1_pretrain_rna.py:299-305): average over ranks, clip, Adam, zero."""
+        for p, a in zip(self.params, self.accs):
+            p.grad = a
+        if self.averager is not None:
+            self.averager.average_()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        torch._foreach_zero_(self.accs)
+        for p in self.params:
+            p.grad = None
+        if self._graph is not None:
+            from . import stack
+            stack.refresh_weights(self.model)                # the graph reads the bf16 copies in place
+
+    def _capture(self, data: torch.Tensor):
+        """Record the micro-step for this batch shape once; the redraw check stays outside the recording."""
+        self._static_in = data.clone()
+        self._static_out = [torch.zeros((), device=data.device), torch.zeros((), device=data.device)]
+        saved = [a.clone() for a in self.accs]
+        performer = getattr(self.model, "performer", None)
+        auto = performer.auto_check_redraw if performer is not None else None
+        if performer is not None:
+            performer.auto_check_redraw = False
+
+        def body():
+            loss, acc = self._forward_backward(self._static_in)
+            self._static_out[0].copy_(loss)
+            self._static_out[1].copy_(acc)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        for a, s_ in zip(self.accs, saved):                  # warm-up and recording passes do not count
+            a.copy_(s_)
+        self._graph, self._graph_shape, self._graph_auto = graph, tuple(data.shape), auto
+
+    def micro_step(self, data: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One pass of s1_pretrain_rna.py:287-305 over a batch of tokens int64 [B, N].  -> (loss / grad_acc,
+        batch accuracy) as device scalars; nothing waits for the device."""
+        self.index += 1
+        if self.use_graph and data.is_cuda:
+            if self._graph is None:
+                self._capture(data)
+            if tuple(data.shape) == self._graph_shape:
+                performer = getattr(self.model, "performer", None)
+                if performer is not None and self._graph_auto:
+                    performer.check_redraw_projections()     # host-side bookkeeping; a redraw needs fresh copies
+                    from . import stack
+                    stack.refresh_weights(self.model)
+                self._static_in.copy_(data)
+                self._graph.replay()
+                loss, acc = self._static_out[0].clone(), self._static_out[1].clone()
+            else:
+                loss, acc = self._eager(data)
+        else:
+            loss, acc = self._eager(data)
+        if self.index % self.grad_acc == 0:
+            self._optimizer_step()
+        return loss, acc
+
+    def _eager(self, data):
+        performer = getattr(self.model, "performer", None)
+        if self._graph is not None and performer is not None:
+            performer.auto_check_redraw = self._graph_auto
+            try:
+                return self._forward_backward(data)
+            finally:
+                performer.auto_check_redraw = False
+        return self._forward_backward(data)
+
+    # ---- epochs -----------------------------------------------------------------------------
+    def _mean_over_ranks(self, value: torch.Tensor) -> float:
+        """utils.get_reduced (utils.py:148-156): sum over ranks / world size (here every rank gets the result)."""
+        t = value.detach().to(torch.float64).reshape(1).clone()
+        if self.world > 1:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item()) / self.world
+
+    def train_epoch(self, batches: Iterable[torch.Tensor]) -> Tuple[float, float]:
+        """s1_pretrain_rna.py:281-322 for one epoch.  -> (training loss as the reference prints it, i.e. the mean
+        of loss / grad_acc times grad_acc; accuracy in percent), both averaged over the ranks; then one
+        scheduler step.  Gradients of an unfinished accumulation window carry over, as in the reference."""
+        self.model.train()
+        self.index = 0
+        running_loss = running_acc = None
+        n = 0
+        for data in batches:
+            loss, acc = self.micro_step(data)
+            running_loss = loss if running_loss is None else running_loss + loss
+            running_acc = acc if running_acc is None else running_acc + acc
+            n += 1
+        if n == 0:
+            raise ValueError("empty epoch")
+        epoch_loss = self._mean_over_ranks(running_loss / n)
+        epoch_acc = self._mean_over_ranks(100 * running_acc / n)
+        self.scheduler.step()
+        return epoch_loss * self.grad_acc, epoch_acc
+
+    @torch.no_grad()
+    def validate(self, batches: Iterable[torch.Tensor], n_total_cells: Optional[int] = None) -> Tuple[float, float]:
+        """s1_pretrain_rna.py:326-355: mean validation loss over the rank's batches, averaged over ranks, and the
+        accuracy over the masked positions of the first ``n_total_cells`` cells of the rank-major concatenation
+        (what distributed_concat keeps, utils.py:158-166).  -> (loss, accuracy in percent)."""
+        was_training = self.model.training
+        self.model.eval()
+        running = None
+        n = 0
+        correct, counted = [], []
+        for data in batches:
+            masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
+            logits = self.model(masked)
+            loss = self.loss_fn(logits, labels, self.pad_id).detach()
+            running = loss if running is None else running + loss
+            n += 1
+            final = s1_predictions(logits)
+            keep = labels != self.pad_id
+            correct.append((keep * (final == labels)).sum(dim=-1))
+            counted.append(keep.sum(dim=-1))
+        if n == 0:
+            raise ValueError("empty validation set")
+        val_loss = self._mean_over_ranks(running / n)
+        per_cell = torch.stack([torch.cat(correct), torch.cat(counted)], dim=1)      # [cells of this rank, 2]
+        if self.world > 1:
+            if per_cell.is_cuda and dist.get_backend(self.group) == "gloo":
+                per_cell = per_cell.cpu()
+            parts = [torch.empty_like(per_cell) for _ in range(self.world)]
+            dist.all_gather(parts, per_cell.contiguous(), group=self.group)
+            per_cell = torch.cat(parts, dim=0)
+        if n_total_cells is not None:
+            per_cell = per_cell[:n_total_cells]
+        tot = per_cell.sum(dim=0)
+        self.model.train(was_training)
+        return val_loss, 100.0 * float(tot[0].item()) / float(tot[1].item())
+
+    # ---- the whole run --------------------------------------------------------------------------
+    def batches_of(self, dataset, batch_size: int, epoch: int, *, shuffle: bool = True, seed: int = 0):
+        """This rank's batches for one epoch: DistributedSampler order (s1_pretrain_rna.py:187-190,280) cut into
+        DataLoader batches (the last one may be smaller).  dataset: ingest.SCDataset (binned on the device, one
+        launch per batch) or an int64 tensor [cells, genes]."""
+        idx = sdist.sampler_indices(len(dataset), self.rank, self.world, shuffle=shuffle, seed=seed, epoch=epoch)
+        for lo in range(0, len(idx), batch_size):
+            sel = idx[lo:lo + batch_size]
+            yield dataset.batch(sel) if hasattr(dataset, "batch") else dataset[sel]
+
+    def fit(self, train_set, val_set, *, epochs: int = 25, batch_size: int = 3, start_epoch: int = 1,
+            valid_every: int = 1, patience: int = 3, ckpt_dir: str = "./saved_model/", model_name: str = "pretrain_rna",
+            log: Callable[[str], None] = print) -> List[dict]:
+        """Epoch loop with validation, checkpoint on improvement and early stopping (s1_pretrain_rna.py:276-387).
+        -> one record per epoch."""
+        best = float("inf")
+        patient = 0
+        history = []
+        for epoch in range(start_epoch, epochs + 1):
+            loss, acc = self.train_epoch(self.batches_of(train_set, batch_size, epoch))
+            rec = {"epoch": epoch, "train_loss": loss, "train_acc": acc, "lr": self.optimizer.param_groups[0]["lr"]}
+            if self.rank == 0:
+                log(f"    ==  Epoch: {epoch} | Training Loss: {loss:.6f} | Accuracy: {acc:6.4f}%  ==")
+            if epoch % valid_every == 0:
+                # the validation sampler is never re-seeded in the reference: epoch 0 order every time
+                vloss, vacc = self.validate(self.batches_of(val_set, batch_size, 0), len(val_set))
+                rec.update(val_loss=vloss, val_acc=vacc)
+                stop = 0
+                if self.rank == 0:
+                    log(f"    ==  Epoch: {epoch} | Validation Loss: {vloss:.6f} | Accuracy: {vacc:6.4f}%  ==")
+                    if vloss < best:
+                        best, patient = vloss, 0
+                        save_checkpoint(os.path.join(ckpt_dir, f"{model_name}.pth"), epoch, self.model, self.optimizer,
+                                        self.scheduler, vloss)
+                        log(f"    == model saved at epoch: {epoch} ==")
+                    else:
+                        patient += 1
+                        stop = int(patient > patience)
+                if self.world > 1:
+                    flag = torch.tensor([stop], dtype=torch.int32)
+                    if dist.get_backend(self.group) != "gloo":
+                        flag = flag.to(next(self.model.parameters()).device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                    stop = int(flag.item())
+                history.append(rec)
+                if stop:
+                    if self.rank == 0:
+                        log(f" Early stopping triggered at epoch {epoch}.")
+                    break
+            else:
+                history.append(rec)
+        return history

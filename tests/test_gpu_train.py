@@ -1,0 +1,99 @@
+"""The S1 driver on the device kernels: graph replay of the micro-step against eager launches (same draws ->
+same weights), and a short end-to-end run from a device-resident CSR matrix through checkpoint and resume."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(n, depth=2, redraw=None):
+    import scmomer_amd as S
+    torch.manual_seed(5)
+    m = S.PerformerLM(num_tokens=7, dim=200, depth=depth, max_seq_len=n, heads=10, local_attn_heads=0,
+                      g2v_position_emb=True, feature_redraw_interval=redraw)
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        m.pos_emb.emb.weight[:n] = torch.randn((n, 200), generator=gen, dtype=torch.float64)
+    return m.to(DEV)
+
+
+def _cells(seed, cells, genes):
+    rng = np.random.default_rng(seed)
+    return ((rng.random((cells, genes)) < 0.3) * rng.gamma(2.0, 1.2, (cells, genes))).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from scmomer_amd import ingest, s1, train
+    return ingest, s1, train
+
+
+def test_graph_replay_equals_eager(mods):
+    ingest, s1, train = mods
+    n, b = 517, 3
+    tok = [s1.bin_s1(torch.from_numpy(_cells(i, b, n))).to(DEV) for i in range(6)]
+    gen = torch.Generator().manual_seed(9)
+    pick = torch.rand((b, n), generator=gen).to(DEV)
+    rep = torch.rand((b, n), generator=gen).to(DEV)
+
+    def fixed_mask(data, mp_, rp_, pad, mask):
+        return s1.data_mask_device(data, mp_, rp_, pad, mask, rand_pick=pick, rand_replace=rep)
+
+    out = []
+    for use_graph in (False, True):
+        m = _model(n)
+        tr = train.S1Trainer(m, learning_rate=0.01, grad_acc=2, use_graph=use_graph, mask_fn=fixed_mask)
+        tr.scheduler.step()                                  # leave the 1e-6 floor so that Adam moves the weights
+        tr.scheduler.step()
+        stats = [tr.micro_step(t) for t in tok]
+        assert tr.index == 6
+        out.append((m.state_dict(), torch.stack([s[0] for s in stats]).cpu(), torch.stack([s[1] for s in stats]).cpu()))
+    (sd_e, loss_e, acc_e), (sd_g, loss_g, acc_g) = out
+    assert torch.isfinite(loss_e).all() and torch.isfinite(acc_e).all()
+    torch.testing.assert_close(loss_g, loss_e, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(acc_g, acc_e, rtol=0, atol=0)
+    moved = 0
+    for k in sd_e:
+        if sd_e[k].dtype == torch.float32:
+            torch.testing.assert_close(sd_g[k], sd_e[k], rtol=1e-4, atol=1e-6)
+            moved += 1
+    assert moved > 20
+    fresh = _model(n).state_dict()                           # three Adam steps at lr ~4e-3 did move the weights
+    k = "performer.net.layers.0.1.fn.fn.w1.weight"
+    assert float((sd_e[k] - fresh[k]).abs().max()) > 1e-3
+
+
+def test_fit_from_device_csr_checkpoint_and_resume(mods, tmp_path):
+    import scipy.sparse as sp
+    ingest, s1, train = mods
+    n = 300
+    train_set = ingest.SCDataset(sp.csr_matrix(_cells(1, 10, n)), 7, device=DEV)
+    val_set = ingest.SCDataset(sp.csr_matrix(_cells(2, 4, n)), 7, device=DEV)
+    m = _model(n, redraw=3)                                  # the projection redraw fires inside the run
+    tr = train.S1Trainer(m, learning_rate=1e-3, grad_acc=2)
+    logs = []
+    hist = tr.fit(train_set, val_set, epochs=2, batch_size=3, ckpt_dir=str(tmp_path), model_name="enc", log=logs.append)
+    assert len(hist) == 2 and all(np.isfinite([h["train_loss"], h["val_loss"], h["train_acc"], h["val_acc"]]).all() for h in hist)
+    assert 0.0 <= hist[0]["val_acc"] <= 100.0
+    train_set.data.raise_on_bad_index()
+    path = os.path.join(tmp_path, "enc.pth")
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert "module.performer.net.layers.1.0.fn.fast_attention.projection_matrix" in ck["model_state_dict"]
+    assert ck["model_state_dict"]["module.pos_emb.emb.weight"].dtype == torch.float64
+    # resume into a fresh replica: same logits as the checkpointed weights give
+    m2 = _model(n, redraw=3)
+    tr2 = train.S1Trainer(m2, learning_rate=1e-3, grad_acc=2)
+    start = train.load_checkpoint(path, m2, tr2.optimizer, tr2.scheduler)
+    assert start == ck["epoch"] + 1
+    m.load_state_dict({k[len("module."):]: v for k, v in ck["model_state_dict"].items()})
+    m.eval(), m2.eval()
+    tok = val_set.batch([0, 1])
+    with torch.no_grad():
+        assert torch.equal(m(tok), m2(tok))
+    assert tr2.optimizer.state_dict()["state"].keys() == ck["optimizer_state_dict"]["state"].keys()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box check: parity tests, then bench with the per-kernel table.  usage: tools/gpu_check.sh TAG [pytest -k expr]
 TAG=$1; K=${2:-""}
-timeout -k 10 600 python -u -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_s1_tail.py tests/test_gpu_ingest.py -m gpu -q -x --timeout 300 --timeout-method thread ${K:+-k "$K"} > gpurun_out/t_$TAG.log 2>&1
+timeout -k 10 600 python -u -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_s1_tail.py tests/test_gpu_ingest.py tests/test_gpu_train.py -m gpu -q -x --timeout 300 --timeout-method thread ${K:+-k "$K"} > gpurun_out/t_$TAG.log 2>&1
 rc=$?; echo "tests exit $rc"; tail -3 gpurun_out/t_$TAG.log
 [ $rc -ne 0 ] && { grep -E "Error|error|assert" gpurun_out/t_$TAG.log | head -20; exit $rc; }
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 --trace-all --no-cpu-baseline > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err

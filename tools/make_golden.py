@@ -184,6 +184,91 @@ def main():
             fx["param:" + kname] = val.numpy()
     np.savez_compressed(os.path.join(out, "scmomer_embed.npz"), **fx)
 
+    # ---- (xi) the S1 loop: schedule, accumulation, clipping, Adam, accuracy, checkpoint layout ------------------
+    # The loop lives inside main() of the reference script, so it is driven here statement by statement with the
+    # reference's own pieces (data_mask, CosineAnnealingWarmupRestarts, the loss, the samplers of torch) on a
+    # stand-in token model; single process (DDP over one rank is the identity).
+    import utils as ref_utils
+    from torch.utils.data import DataLoader, DistributedSampler
+    sched_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sched = ref_utils.CosineAnnealingWarmupRestarts(sched_opt, first_cycle_steps=15, cycle_mult=2, max_lr=1e-4,
+                                                    min_lr=1e-6, warmup_steps=5, gamma=0.9)
+    lrs = [sched_opt.param_groups[0]["lr"]]
+    for _ in range(120):
+        sched.step()
+        lrs.append(sched_opt.param_groups[0]["lr"])
+    sched_state = {k: v for k, v in sched.state_dict().items() if isinstance(v, (int, float))}
+    jump = []
+    for e in (3, 14, 15, 16, 44, 45, 46, 104, 105, 200):
+        o2 = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+        s2 = ref_utils.CosineAnnealingWarmupRestarts(o2, first_cycle_steps=15, cycle_mult=2, max_lr=1e-4, min_lr=1e-6,
+                                                     warmup_steps=5, gamma=0.9)
+        s2.step(e)
+        jump.append([e, o2.param_groups[0]["lr"], s2.cycle, s2.step_in_cycle, s2.cur_cycle_steps])
+
+    grad_acc, batch_size, epochs, genes = 2, 3, 3, 64
+    train_tok, val_tok = O.standin_cells(7, 14, genes), O.standin_cells(8, 5, genes)
+    model = O.standin_lm(99)
+    torch.manual_seed(123)
+    train_sampler = DistributedSampler(train_tok, num_replicas=1, rank=0)
+    val_sampler = DistributedSampler(val_tok, num_replicas=1, rank=0)
+    train_loader = DataLoader(train_tok, batch_size=batch_size, sampler=train_sampler)
+    val_loader = DataLoader(val_tok, batch_size=batch_size, sampler=val_sampler)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4 * 300)    # a visible step size for a 3-epoch fixture
+    scheduler = ref_utils.CosineAnnealingWarmupRestarts(optimizer, first_cycle_steps=15, cycle_mult=2,
+                                                        max_lr=1e-4 * 300, min_lr=1e-6, warmup_steps=5, gamma=0.9)
+    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=6, reduction="mean")
+    softmax = torch.nn.Softmax(dim=-1)
+    rec = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "lr_after_epoch": []}
+    for i in range(1, epochs + 1):
+        train_loader.sampler.set_epoch(i)
+        model.train()
+        running_loss = cum_acc = 0.0
+        for index, data in enumerate(train_loader):
+            index += 1
+            masked_input, labels = s1.data_mask(data, 0.15, 0.9, 6, 6)
+            logits = model(masked_input)
+            loss = loss_fn(logits.transpose(1, 2), labels) / grad_acc
+            loss.backward()
+            if index % grad_acc == 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), int(1e2))
+                optimizer.step()
+                optimizer.zero_grad()
+            running_loss += loss.item()
+            final = softmax(logits)[..., 1:-1].argmax(dim=-1) + 1
+            pred_num = (labels != 6).sum(dim=-1)
+            correct_num = ((labels != 6) * (final == labels)).sum(dim=-1)
+            cum_acc += torch.true_divide(correct_num, pred_num).mean().item()
+        rec["train_loss"].append(running_loss / len(train_loader) * grad_acc)
+        rec["train_acc"].append(100 * cum_acc / len(train_loader))
+        scheduler.step()
+        rec["lr_after_epoch"].append(optimizer.param_groups[0]["lr"])
+        model.eval()
+        val_running, preds, truths = 0.0, [], []
+        with torch.no_grad():
+            for val_index, data in enumerate(val_loader):
+                val_index += 1
+                masked_input, labels = s1.data_mask(data, 0.15, 0.9, 6, 6)
+                logits = model(masked_input)
+                val_running += loss_fn(logits.transpose(1, 2), labels).item()
+                preds.append(softmax(logits)[..., 1:-1].argmax(dim=-1) + 1)
+                truths.append(labels)
+        preds, truths = torch.cat(preds), torch.cat(truths)
+        rec["val_loss"].append(val_running / val_index)
+        rec["val_acc"].append(100 * ((truths != 6) * (preds == truths)).sum().item() / (truths != 6).sum().item())
+    fx = {k: np.asarray(v, dtype=np.float64) for k, v in rec.items()}
+    fx.update({"sched_lrs": np.asarray(lrs, dtype=np.float64), "sched_jump": np.asarray(jump, dtype=np.float64),
+               "sched_state_keys": np.asarray(sorted(sched_state)), "grad_acc": np.int64(grad_acc),
+               "batch_size": np.int64(batch_size), "epochs": np.int64(epochs), "genes": np.int64(genes),
+               "lr": np.float64(1e-4 * 300)})
+    for k, v in sched_state.items():
+        fx["sched_state:" + k] = np.float64(v)
+    for k, v in model.state_dict().items():
+        fx["final:" + k] = v.numpy()
+    for k, v in optimizer.state_dict()["state"].items():
+        fx[f"adam_exp_avg:{k}"] = v["exp_avg"].numpy()
+    np.savez_compressed(os.path.join(out, "s1_loop.npz"), **fx)
+
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)))
 
