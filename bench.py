@@ -139,72 +139,28 @@ def main():
 
     _say("process group up")
     from scmomer_amd import dist as sdist
-    from scmomer_amd import ops, s1, stack
+    from scmomer_amd import ops, s1, train
     torch.manual_seed(2024 + rank)
     model = build_model(device)
     model.train()
-    params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4)
-    # Gradient accumulation over the grad_acc micro-steps: backward hands each parameter a fresh gradient
-    # (p.grad is None, so autograd stores it without an add kernel) and ONE multi-tensor add folds all of them into
-    # static accumulators; the accumulators become p.grad for the all-reduce / clip / Adam of the sync step.
-    accs = [torch.zeros_like(p) for p in params]
-    averager = sdist.GradientAverager(params)   # one flat bucket, one all-reduce per optimizer step
+    # The shipped S1 driver runs the step: mask -> encoder forward -> CE / grad_acc -> backward -> accuracy, with
+    # gradients folded into static accumulators by one multi-tensor add; every grad_acc-th micro-step it averages
+    # the gradients over the ranks (one flat all-reduce), clips, applies Adam and refreshes the bf16 weight copies
+    # (s1_pretrain_rna.py:287-312).  The micro-step is launch-bound when driven from Python (about 250 kernel
+    # launches), so the driver records it once into a HIP graph and replays it.
+    trainer = train.S1Trainer(model, learning_rate=1e-4, grad_acc=args.grad_acc, mask_prob=0.15, replace_prob=0.9,
+                              use_graph=not args.eager)
 
     # each rank owns its own shard of synthetic cells (resident in HBM before timing starts)
     n_batches = 4
     data = [s1.synthetic_tokens(1000 * rank + i, args.batch, N_GENES, device) for i in range(n_batches)]
-    static_tok = data[0].clone()
-    static_loss = torch.zeros((), device=device)
-
-    def micro_step():
-        """mask -> encoder forward -> CE -> backward (gradients accumulate), s1_pretrain_rna.py:290-302"""
-        masked, labels = s1.data_mask_device(static_tok, 0.15, 0.9, 6, 6)
-        loss = s1.masked_cross_entropy(model(masked), labels, 6) / args.grad_acc
-        loss.backward()
-        torch._foreach_add_(accs, [p.grad for p in params])
-        for p in params:
-            p.grad = None
-        static_loss.copy_(loss.detach())
-
-    def sync_step():
-        """every grad_acc micro-steps: average gradients over ranks (what DDP's reducer does on the sync
-        step, s1_pretrain_rna.py:299-305), clip, Adam, zero"""
-        for p, a in zip(params, accs):
-            p.grad = a
-        averager.average_()
-        torch.nn.utils.clip_grad_norm_(params, int(1e2))
-        opt.step()
-        torch._foreach_zero_(accs)
-        for p in params:
-            p.grad = None
-        stack.refresh_weights(model)       # bf16 operand copies of the updated weights (in place, outside the graph)
-
-    # The micro-step is launch-bound when driven from Python (about 250 kernel launches), so it is captured
-    # once into a HIP graph and replayed; the bf16 weight copies it reads are refreshed after each Adam step.
-    graph = None
-    if not args.eager:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                micro_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            micro_step()
-        torch._foreach_zero_(accs)         # warm-up and capture passes do not count
+    last = {}
 
     def step(i):
-        static_tok.copy_(data[i % n_batches])
-        if graph is not None:
-            graph.replay()
-        else:
-            micro_step()
-        if (i + 1) % args.grad_acc == 0:
-            sync_step()
+        last["loss"], last["acc"] = trainer.micro_step(data[i % n_batches])
 
+    trainer.prepare(data[0])
+    graph = None if args.eager else True
     _say("graph captured" if graph is not None else "eager mode")
     for i in range(args.warmup):
         step(i)
@@ -223,7 +179,8 @@ def main():
     dt = time.perf_counter() - t0
     _say("timed region done")
     dt = sdist.max_over_ranks(dt, device)
-    final_loss = float(static_loss.item()) * args.grad_acc
+    final_loss = float(last["loss"].item()) * args.grad_acc
+    final_acc = float(last["acc"].item())
 
     # Per-kernel durations: HIP events on the launch stream around every launch, taken on a few eager
     # micro-steps right after the timed region (event pairs cannot be read back from inside a replayed graph;
@@ -232,8 +189,7 @@ def main():
     ops.trace_enable("all")
     traced_steps = 3
     for i in range(traced_steps):
-        static_tok.copy_(data[i % n_batches])
-        micro_step()
+        trainer._forward_backward(data[i % n_batches])
     torch.cuda.synchronize()
     ops.trace_enable(None)
     trace = ops.trace_collect()
@@ -275,12 +231,13 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic",
                "config": {"workload": "S1 RNA masked-autoencoding pretrain micro-step (mask_prob 0.15): mask + "
-                                      "Performer encoder fwd + CE + bwd; clip + Adam every grad_acc steps",
+                                      "Performer encoder fwd + CE + bwd + accuracy; gradient average, clip + Adam "
+                                      "every grad_acc steps (scmomer_amd.train.S1Trainer)",
                           "cells_per_gpu_per_step": args.batch, "gene_tokens": N_GENES, "depth": 6, "dim": 200,
                           "heads": 10, "nb_features": 266, "grad_acc": args.grad_acc,
                           "parallelism": f"dp{world}", "feature_redraw": "disabled",
                           "launch": "eager" if args.eager else "hip-graph replay of the micro-step"},
-               "final_loss": final_loss, "roofline": roof, "cpu_baseline": base, "kernels": kernels}
+               "final_loss": final_loss, "final_batch_accuracy": final_acc, "roofline": roof, "cpu_baseline": base, "kernels": kernels}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

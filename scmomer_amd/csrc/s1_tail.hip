@@ -195,7 +195,51 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// accuracy of the S1 loop (s1_pretrain_rna.py:308-312): prediction = 1 + argmax over the classes 1..C-2 (the
+// first maximum wins, as torch.argmax), counted where label != pad.  One 256-thread workgroup per cell:
+// counts[cell] = {correct, counted}, ratio[cell] = correct / counted (nan for a cell with nothing masked).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s1_accuracy_kernel(const float* __restrict__ logits,
+                                                          const int64_t* __restrict__ labels, int N, int C,
+                                                          long long pad_id, float* __restrict__ ratio,
+                                                          int* __restrict__ counts) {
+  __shared__ int rc[4], rn[4];
+  const long base = (long)blockIdx.x * N;
+  int correct = 0, counted = 0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const long long lab = labels[base + i];
+    if (lab == pad_id) continue;
+    const float* v = logits + (base + i) * C;
+    int best = 1;
+    float bv = v[1];
+    for (int c = 2; c < C - 1; ++c) {
+      const float x = v[c];
+      if (x > bv) { bv = x; best = c; }
+    }
+    counted += 1;
+    correct += (best == (int)lab) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { correct += __shfl_xor(correct, o); counted += __shfl_xor(counted, o); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { rc[w] = correct; rn[w] = counted; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int c = (rc[0] + rc[1]) + (rc[2] + rc[3]), n = (rn[0] + rn[1]) + (rn[2] + rn[3]);
+    counts[2 * blockIdx.x] = c;
+    counts[2 * blockIdx.x + 1] = n;
+    ratio[blockIdx.x] = (float)c / (float)n;
+  }
+}
+
 // ---------------------------------------------------------------- host launchers
+hipError_t s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, long long pad_id, float* ratio,
+                       int* counts, hipStream_t s) {
+  Traced tr(K_CE, 0, s);
+  hipLaunchKernelGGL(s1_accuracy_kernel, dim3(B), dim3(256), 0, s, logits, labels, N, C, pad_id, ratio, counts);
+  return hipGetLastError();
+}
 hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,
                    float replace_prob, int max_masked, long long pad_id, long long mask_id, int64_t* masked,
                    int64_t* labels, hipStream_t s) {

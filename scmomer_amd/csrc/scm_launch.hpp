@@ -113,6 +113,8 @@ hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, lon
                   float* out, hipStream_t s);
 hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, const float* dloss,
                   const float* loss_count, float* dlogits, hipStream_t s);
+hipError_t s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, long long pad_id, float* ratio,
+                       int* counts, hipStream_t s);
 
 // ingest.hip
 constexpr int BIN_MAX_GENES = 36864;   // dense f32 row of one cell in LDS (144 KB)

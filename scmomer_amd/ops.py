@@ -286,6 +286,18 @@ def ce_bwd(logits, labels, ignore_index: int, dloss: torch.Tensor, loss_count: t
     return dlogits
 
 
+def s1_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int):
+    """-> (ratio f32 [B] = correct / counted per cell, counts int32 [B,2] = (correct, counted))"""
+    _req(logits, F32, "logits")
+    _req(labels, torch.int64, "labels")
+    b, n, c = logits.shape
+    ratio = torch.empty(b, dtype=F32, device=logits.device)
+    counts = torch.empty((b, 2), dtype=torch.int32, device=logits.device)
+    check(lib.scm_s1_accuracy(_p(logits), _p(labels), b, n, c, pad_id, _p(ratio), _p(counts), _stream()),
+          "scm_s1_accuracy")
+    return ratio, counts
+
+
 # ----------------------------------------------------------------------------- ingest, projection redraw
 RULE_S1, RULE_SCMOMER = 0, 1
 

@@ -112,11 +112,22 @@ def s1_predictions(logits: torch.Tensor) -> torch.Tensor:
 def s1_batch_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int) -> torch.Tensor:
     """s1_pretrain_rna.py:308-312: per cell, correct / predicted over the masked positions; mean over the cells
     (a cell without masked positions yields nan, as in the reference).  Device scalar."""
+    if logits.is_cuda and logits.dim() == 3 and logits.dtype == torch.float32:
+        from . import ops
+        return ops.s1_accuracy(logits.contiguous(), labels.contiguous(), pad_id)[0].mean()   # one kernel per batch
+    correct_num, pred_num = _cell_counts(logits, labels, pad_id)
+    return torch.true_divide(correct_num, pred_num).mean()
+
+
+def _cell_counts(logits: torch.Tensor, labels: torch.Tensor, pad_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(correct, counted) per cell, int64 [B] each."""
+    if logits.is_cuda and logits.dim() == 3 and logits.dtype == torch.float32:
+        from . import ops
+        counts = ops.s1_accuracy(logits.contiguous(), labels.contiguous(), pad_id)[1].to(torch.int64)
+        return counts[:, 0], counts[:, 1]
     final = s1_predictions(logits)
     counted = labels != pad_id
-    pred_num = counted.sum(dim=-1)
-    correct_num = (counted * (final == labels)).sum(dim=-1)
-    return torch.true_divide(correct_num, pred_num).mean()
+    return (counted * (final == labels)).sum(dim=-1), counted.sum(dim=-1)
 
 
 def freeze_for_finetune(model) -> Tuple[int, int]:
@@ -269,6 +280,12 @@ class S1Trainer:
             a.copy_(s_)
         self._graph, self._graph_shape, self._graph_auto = graph, tuple(data.shape), auto
 
+    def prepare(self, example: torch.Tensor) -> None:
+        """Record the micro-step graph for batches shaped like ``example`` now (otherwise the first micro_step
+        does it).  The warm-up passes of the recording leave weights and accumulators untouched."""
+        if self.use_graph and example.is_cuda and self._graph is None:
+            self._capture(example)
+
     def micro_step(self, data: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """One pass of s1_pretrain_rna.py:287-305 over a batch of tokens int64 [B, N].  -> (loss / grad_acc,
         batch accuracy) as device scalars; nothing waits for the device."""
@@ -349,10 +366,9 @@ class S1Trainer:
             loss = self.loss_fn(logits, labels, self.pad_id).detach()
             running = loss if running is None else running + loss
             n += 1
-            final = s1_predictions(logits)
-            keep = labels != self.pad_id
-            correct.append((keep * (final == labels)).sum(dim=-1))
-            counted.append(keep.sum(dim=-1))
+            c_, n_ = _cell_counts(logits, labels, self.pad_id)
+            correct.append(c_)
+            counted.append(n_)
         if n == 0:
             raise ValueError("empty validation set")
         val_loss = self._mean_over_ranks(running / n)

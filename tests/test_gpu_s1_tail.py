@@ -95,3 +95,24 @@ def test_cross_entropy_matches_torch(s1, b, n, c, frac):
         return
     assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
     assert float((logits.grad - ref_logits.grad).abs().max()) <= 1e-5 * float(ref_logits.grad.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("b,n,c", [(3, 16906, 7), (2, 100, 7), (1, 1, 3), (4, 513, 12)])
+def test_accuracy_matches_the_loop_definition(b, n, c):
+    """prediction = 1 + argmax(softmax(logits)[..., 1:-1]) counted where label != pad (bit-exact counts)"""
+    from scmomer_amd import ops
+    g = torch.Generator().manual_seed(b * n + c)
+    logits = torch.randn((b, n, c), generator=g)
+    logits[0, 0, 1:3] = 0.25                                  # a tie: the first maximum wins
+    labels = torch.randint(1, c - 1, (b, n), generator=g)
+    pad = c - 1
+    labels[torch.rand((b, n), generator=g) > 0.2] = pad
+    if b > 1:
+        labels[1] = pad                                       # a cell with nothing masked: ratio is nan
+    ratio, counts = ops.s1_accuracy(logits.to(DEV), labels.to(DEV), pad)
+    final = logits[..., 1:-1].argmax(dim=-1) + 1
+    keep = labels != pad
+    want_n = keep.sum(-1)
+    want_c = (keep * (final == labels)).sum(-1)
+    assert torch.equal(counts.cpu()[:, 0].long(), want_c) and torch.equal(counts.cpu()[:, 1].long(), want_n)
+    torch.testing.assert_close(ratio.cpu(), torch.true_divide(want_c, want_n), equal_nan=True, rtol=1e-6, atol=0)
