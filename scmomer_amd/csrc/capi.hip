@@ -317,10 +317,10 @@ int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int
 }
 
 int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, int64_t pad_id, float* ratio,
-                    int* counts, void* stream) {
-  SCM_REQ(logits && labels && ratio && counts, "scm_s1_accuracy: null pointer");
+                    int* counts, int* ws, void* stream) {
+  SCM_REQ(logits && labels && ratio && counts && ws, "scm_s1_accuracy: null pointer");
   SCM_REQ(B > 0 && N > 0 && C >= 3 && C <= 64, "scm_s1_accuracy: need B, N > 0 and 3 <= C <= 64");
-  SCM_HIP(s1_accuracy(logits, labels, B, N, C, pad_id, ratio, counts, (hipStream_t)stream), "scm_s1_accuracy");
+  SCM_HIP(s1_accuracy(logits, labels, B, N, C, pad_id, ratio, counts, ws, (hipStream_t)stream), "scm_s1_accuracy");
   return 0;
 }
 

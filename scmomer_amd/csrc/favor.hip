@@ -396,47 +396,10 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
   const int tid = threadIdx.x, bh = blockIdx.x, tile = blockIdx.y;
   const float* base = part + (long)bh * nchunks * CTX_PART;
   __shared__ float wmaxs[4];
-  float gmax = 0.f;
-  if (stab) {   // max over all partial stabilisers, by the whole workgroup
-    float m = -INFINITY;
-    for (int i = tid; i < nstab; i += 256) m = fmaxf(m, stab[i]);
-    m = wave_max(m);
-    if ((tid & 63) == 0) wmaxs[tid >> 6] = m;
-    __syncthreads();
-    gmax = fmaxf(fmaxf(wmaxs[0], wmaxs[1]), fmaxf(wmaxs[2], wmaxs[3]));
-    if (tile == 0 && tid == 0) gmax_out[(long)bh * SUMS_STRIDE + DH + 1] = gmax;   // for the backward passes
-  }
-  // per-feature factor exp(b_m - c max) of this tile's 32 features (1 when there is no stabiliser: backward)
   __shared__ float fscale[32];
-  if (tid < 32) {
-    float f = 1.f;
-    if (stab) {
-      const bf16* orow = omega_b + (long)(32 * tile + tid) * DH;
-      float ss = 0.f;
-      for (int d = 0; d < DH; ++d) { const float v = (float)orow[d]; ss += v * v; }
-      f = exp2_fast((0.5f * ss - CNORM * gmax) * LOG2E);
-    }
-    fscale[tid] = f;
-  }
-  if (tid < DH) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NF * DH + tid];   // row of the ones feature
-    ysum[tid] = s;
-  }
-  if (tid == 64) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NF];    // z slot of the ones feature
-    wsum = s;
-  }
-  __syncthreads();
-  if (tid < 32) {
-    const int m = 32 * tile + tid;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + m];
-    const float v = (m < NF) ? fscale[tid] * s + KEPS * wsum : 0.f;
-    zl[tid] = v;
-    zz[(long)bh * NFP + m] = v;
-  }
+  __shared__ float zraw[32];
+  // Everything this workgroup reads is independent of what it computes, so all loads are issued up front (the
+  // chunk sums of its 32 x 64 context entries first) and the dependent steps follow after ONE round trip.
   const int d = tid & 63, q = tid >> 6;
   float acc8[8];
 #pragma unroll
@@ -445,6 +408,47 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
     const float* rec = base + (long)c * CTX_PART + (32 * tile + q) * DH + d;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc8[i] += rec[4 * i * DH];
+  }
+  float m = -INFINITY;
+  if (stab)
+    for (int i = tid; i < nstab; i += 256) m = fmaxf(m, stab[i]);
+  if (tid < DH) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NF * DH + tid];   // row of the ones feature
+    ysum[tid] = s;
+  } else if (tid == 64) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NF];    // z slot of the ones feature
+    wsum = s;
+  } else if (tid >= 128 && tid < 160) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + 32 * tile + (tid - 128)];
+    zraw[tid - 128] = s;
+  }
+  // |w_m|^2 of this tile's 32 features: 8 threads per feature, 16 bytes each
+  float ss = 0.f;
+  if (stab) {
+    const bf16x8 ov = *(const bf16x8*)(omega_b + (long)(32 * tile + (tid >> 3)) * DH + 8 * (tid & 7));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = (float)ov[j]; ss += v * v; }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+  }
+  float gmax = 0.f;
+  if (stab) {   // max over all partial stabilisers, by the whole workgroup
+    m = wave_max(m);
+    if ((tid & 63) == 0) wmaxs[tid >> 6] = m;
+    __syncthreads();
+    gmax = fmaxf(fmaxf(wmaxs[0], wmaxs[1]), fmaxf(wmaxs[2], wmaxs[3]));
+    if (tile == 0 && tid == 0) gmax_out[(long)bh * SUMS_STRIDE + DH + 1] = gmax;   // for the backward passes
+  }
+  // per-feature factor exp(b_m - c max) of this tile's 32 features (1 when there is no stabiliser: backward)
+  if ((tid & 7) == 0) fscale[tid >> 3] = stab ? exp2_fast((0.5f * ss - CNORM * gmax) * LOG2E) : 1.f;
+  __syncthreads();
+  if (tid < 32) {
+    const int mm = 32 * tile + tid;
+    const float v = (mm < NF) ? fscale[tid] * zraw[tid] + KEPS * wsum : 0.f;
+    zl[tid] = v;
+    zz[(long)bh * NFP + mm] = v;
   }
   float csum = 0.f;
 #pragma unroll

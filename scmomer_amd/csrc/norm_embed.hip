@@ -316,9 +316,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // Column sums of the per-workgroup partial rows, for up to 4 column segments with their own outputs:
 // seg.out[k][i] (+)= sum_b partial[b][seg.lo[k] + i], i < seg.hi[k] - seg.lo[k].  One launch covers all segments
 // (blockIdx.y = segment).  Workgroup = 32 columns x 8 row groups; fixed summation order.
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, int nblocks, int width,
-                                                            ColsumSegs seg, int accumulate) {
-  __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ partial, int nblocks, int width,
+                                                             ColsumSegs seg, int accumulate) {
+  // 32 columns x 32 row groups per workgroup: every thread sums nblocks/32 rows with 4 loads in flight, so the
+  // dependent-latency chain is a handful of round trips
+  __shared__ float red[32][33];
   const int k = blockIdx.y;
   const int lo = seg.lo[k], n = seg.hi[k] - lo;
   float* __restrict__ out = seg.out[k];
@@ -329,19 +331,20 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   if (i < n) {
     const float* p = partial + lo + i;
     int b = rg;
-    for (; b + 24 < nblocks; b += 32) {
-      const float a0 = p[(long)b * width], a1 = p[(long)(b + 8) * width];
-      const float a2 = p[(long)(b + 16) * width], a3 = p[(long)(b + 24) * width];
+    for (; b + 96 < nblocks; b += 128) {
+      const float a0 = p[(long)b * width], a1 = p[(long)(b + 32) * width];
+      const float a2 = p[(long)(b + 64) * width], a3 = p[(long)(b + 96) * width];
       s += (a0 + a1) + (a2 + a3);
     }
-    for (; b < nblocks; b += 8) s += p[(long)b * width];
+    for (; b < nblocks; b += 32) s += p[(long)b * width];
   }
   red[rg][c] = s;
   __syncthreads();
   if (rg == 0 && i < n) {
-    float t = 0.f;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][c];
+    for (int r = 0; r < 32; r += 4) { t0 += red[r][c]; t1 += red[r + 1][c]; t2 += red[r + 2][c]; t3 += red[r + 3][c]; }
+    const float t = (t0 + t1) + (t2 + t3);
     out[i] = accumulate ? out[i] + t : t;
   }
 }
@@ -401,7 +404,7 @@ hipError_t colsum_reduce(const float* partial, int nblocks, int width, const Col
     if (seg.out[k] && seg.hi[k] - seg.lo[k] > widest) widest = seg.hi[k] - seg.lo[k];
   if (widest == 0) return hipSuccess;
   Traced tr(K_COLSUM, 0, s);
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((widest + 31) / 32, nseg), dim3(256), 0, s, partial, nblocks, width,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((widest + 31) / 32, nseg), dim3(1024), 0, s, partial, nblocks, width,
                      seg, accumulate);
   return hipGetLastError();
 }

@@ -197,17 +197,19 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 
 // ------------------------------------------------------------------------------------------
 // accuracy of the S1 loop (s1_pretrain_rna.py:308-312): prediction = 1 + argmax over the classes 1..C-2 (the
-// first maximum wins, as torch.argmax), counted where label != pad.  One 256-thread workgroup per cell:
-// counts[cell] = {correct, counted}, ratio[cell] = correct / counted (nan for a cell with nothing masked).
+// first maximum wins, as torch.argmax), counted where label != pad.  grid (chunks, cells): integer atomics into
+// counts[cell] = {correct, counted} (zeroed by the launcher); the workgroup that arrives last for a cell writes
+// ratio[cell] = correct / counted (nan for a cell with nothing masked).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void s1_accuracy_kernel(const float* __restrict__ logits,
                                                           const int64_t* __restrict__ labels, int N, int C,
                                                           long long pad_id, float* __restrict__ ratio,
-                                                          int* __restrict__ counts) {
+                                                          int* __restrict__ counts, int* __restrict__ arrivals) {
   __shared__ int rc[4], rn[4];
-  const long base = (long)blockIdx.x * N;
+  const int cell = blockIdx.y;
+  const long base = (long)cell * N;
   int correct = 0, counted = 0;
-  for (int i = threadIdx.x; i < N; i += 256) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
     const long long lab = labels[base + i];
     if (lab == pad_id) continue;
     const float* v = logits + (base + i) * C;
@@ -226,18 +228,27 @@ __global__ __launch_bounds__(256) void s1_accuracy_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) { rc[w] = correct; rn[w] = counted; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int c = (rc[0] + rc[1]) + (rc[2] + rc[3]), n = (rn[0] + rn[1]) + (rn[2] + rn[3]);
-    counts[2 * blockIdx.x] = c;
-    counts[2 * blockIdx.x + 1] = n;
-    ratio[blockIdx.x] = (float)c / (float)n;
+    atomicAdd(&counts[2 * cell], (rc[0] + rc[1]) + (rc[2] + rc[3]));
+    atomicAdd(&counts[2 * cell + 1], (rn[0] + rn[1]) + (rn[2] + rn[3]));
+    __threadfence();
+    if (atomicAdd(&arrivals[cell], 1) == (int)gridDim.x - 1) {   // every other workgroup's adds are visible
+      const int c = atomicAdd(&counts[2 * cell], 0), n = atomicAdd(&counts[2 * cell + 1], 0);
+      ratio[cell] = (float)c / (float)n;
+    }
   }
 }
 
 // ---------------------------------------------------------------- host launchers
 hipError_t s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, long long pad_id, float* ratio,
-                       int* counts, hipStream_t s) {
+                       int* counts, int* arrivals, hipStream_t s) {
   Traced tr(K_CE, 0, s);
-  hipLaunchKernelGGL(s1_accuracy_kernel, dim3(B), dim3(256), 0, s, logits, labels, N, C, pad_id, ratio, counts);
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * 2 * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(arrivals, 0, (size_t)B * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  const int chunks = (N + 255) / 256 < 64 ? (N + 255) / 256 : 64;
+  hipLaunchKernelGGL(s1_accuracy_kernel, dim3(chunks, B), dim3(256), 0, s, logits, labels, N, C, pad_id, ratio, counts,
+                     arrivals);
   return hipGetLastError();
 }
 hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,

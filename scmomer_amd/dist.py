@@ -71,14 +71,15 @@ class GradientAverager:
 
     @torch.no_grad()
     def average_(self) -> None:
-        """p.grad <- mean over ranks of p.grad, for every parameter (a missing grad counts as zero)."""
+        """p.grad <- mean over ranks of p.grad, for every parameter (a missing grad counts as zero).  A caller that
+        accumulates straight into ``views`` (p.grad is the view itself) pays no gather/scatter copies: the
+        all-reduce runs on the bucket in place."""
         if self.world == 1:
             return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
+        in_place = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+        if not in_place:
+            src = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self.views)]
+            torch._foreach_copy_(self.views, src)
         if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
             # CPU-only backend (rehearsals on a box without RCCL peers): stage the bucket through host memory
             host = self.flat.cpu()
@@ -87,11 +88,11 @@ class GradientAverager:
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        if not in_place:
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    p.grad = v.clone()
+            torch._foreach_copy_([p.grad for p in self.params], self.views)
 
 
 def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group: Optional[dist.ProcessGroup] = None):

@@ -217,8 +217,9 @@ class S1Trainer:
         self.scheduler = CosineAnnealingWarmupRestarts(self.optimizer, first_cycle_steps=15, cycle_mult=2,
                                                        max_lr=learning_rate, min_lr=1e-6, warmup_steps=5, gamma=0.9)
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
-        self.accs = [torch.zeros_like(p) for p in self.params]
         self.averager = sdist.GradientAverager(self.params, group) if self.params else None
+        # the accumulators ARE the slices of the all-reduce bucket: the exchange needs no gather/scatter copies
+        self.accs = list(self.averager.views) if self.averager is not None else []
         sdist.broadcast_parameters(list(model.parameters()) + list(model.buffers()), src=0, group=group)
         self.index = 0                                       # micro-steps since the start of the epoch
         self.use_graph = use_graph
