@@ -171,6 +171,14 @@ int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W, i
   if (epi == SCM_EPI_GELU_DUAL) SCM_REQ(out1 && ldo1 >= N, "scm_gemm_nt: GELU_DUAL needs out1");
   if (epi == SCM_EPI_DGELU) SCM_REQ(pre && ldp >= N, "scm_gemm_nt: DGELU needs pre");
   if (resid) SCM_REQ(ldr >= N, "scm_gemm_nt: ldr < N");
+  {  // the kernels address every matrix through 32-bit byte offsets (buffer resources): extents must stay below 4 GiB
+    const int64_t lim = (int64_t)1 << 32;
+    const int64_t out_es = (epi == SCM_EPI_F32 || epi == SCM_EPI_F32_BIAS_RES) ? 4 : 2;
+    SCM_REQ(((int64_t)(M - 1) * lda + K) * (a_f32 ? 4 : 2) < lim && ((int64_t)(N - 1) * ldw + K) * 2 < lim &&
+                ((int64_t)(M - 1) * ldo0 + N) * out_es < lim && (!out1 || ((int64_t)(M - 1) * ldo1 + N) * 2 < lim) &&
+                (!resid || ((int64_t)(M - 1) * ldr + N) * 4 < lim) && (!pre || ((int64_t)(M - 1) * ldp + N) * 2 < lim),
+            "scm_gemm_nt: a matrix extends beyond 4 GiB; split the rows (M=%d)", M);
+  }
   GemmEpi e{out0, (long)ldo0, out1, (long)ldo1, bias, resid, (long)ldr, (const bf16*)pre, (long)ldp};
   SCM_HIP(gemm_nt(epi, a_f32, A, lda, W, ldw, M, N, K, e, (hipStream_t)stream), "scm_gemm_nt");
   return 0;
@@ -185,6 +193,8 @@ int scm_wgrad(const void* Pm, int64_t ldp, const void* Qm, int64_t ldq, int q_f3
           "scm_wgrad: need P%%8==0, Q<=200, Q%%8==0 (P=%d Q=%d)", P, Q);
   SCM_REQ(ldp % 8 == 0 && ldp >= P && ldq >= Q && ldq % 8 == 0 && aligned16(Pm) && aligned16(Qm),
           "scm_wgrad: bad leading dimension or alignment");
+  SCM_REQ(((T - 1) * ldp + P) * 2 < ((int64_t)1 << 32) && ((T - 1) * ldq + Q) * (q_f32 ? 4 : 2) < ((int64_t)1 << 32),
+          "scm_wgrad: an operand extends beyond 4 GiB; split the rows");
   hipStream_t s = (hipStream_t)stream;
   SCM_HIP(wgrad(Pm, ldp, Qm, ldq, q_f32, bias_grad ? 1 : 0, (int)T, P, Q, slices, ws, s), "scm_wgrad");
   SCM_HIP(wgrad_reduce(ws, slices, P, Q, grad, bias_grad, trans, accumulate, s), "scm_wgrad(reduce)");

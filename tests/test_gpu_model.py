@@ -189,6 +189,30 @@ def test_full_size_forward_vs_oracle():
     assert (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean() > 0.97
 
 
+def test_extraction_batch_of_24_cells_full_length():
+    """a large no-grad batch at the full gene count (one chunk per (cell, head) in every attention pass): the first
+    cell, run inside the batch, agrees with the CPU oracle of the same batch's first cells within the bf16
+    tolerance, the batch is reproducible, and a batch beyond the addressing limit is refused with a clear message"""
+    n, depth = 16906, 2
+    p = O.make_params(77, depth=depth, max_seq_len=n)
+    cells = O.synthetic_cells(77, 24, n)
+    tokens = torch.from_numpy(np.minimum(cells, 5).astype(np.int64))
+    m = build(p, n, depth, "linear").eval()
+    with torch.no_grad():
+        out = m(tokens.to(DEV))
+        again = m(tokens.to(DEV))
+        pair = m(tokens[:2].to(DEV))
+    assert torch.isfinite(out).all() and torch.equal(out, again)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = O.performer_lm_forward(tokens[:2], p, depth=depth, heads=10)
+    assert relmax(pair, ref) < TOL_MAX and rell2(pair, ref) < TOL_L2
+    # inside the larger batch the key stabiliser is the max over 24 cells instead of 2: a tiny, bounded difference
+    assert relmax(out[:2], ref) < 2 * TOL_MAX
+    with pytest.raises(ValueError, match="4 GiB"):
+        m(torch.zeros((70, n), dtype=torch.int64, device=DEV))
+
+
 def test_scmomer_cell_embedding_matches_reference_fixture(golden_dir):
     """scMomer.get_cell_embedding (RNA-only configuration, 16906 genes, depth 6) on the kernels vs the output of
     the reference itself on the same seeded parameters.  Stated bf16 tolerance: relative L2 <= 4e-3, max-abs error
