@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-all", action="store_true", help="time every kernel (per-kernel table to stderr)")
     ap.add_argument("--eager", action="store_true", help="drive every launch from Python instead of a HIP graph")
+    ap.add_argument("--mode", choices=("train", "extract"), default="train",
+                    help="train: the S1 micro-step (the headline metric); extract: forward-only cell-embedding "
+                         "extraction (scMomer.get_cell_embedding), a secondary figure")
     return ap.parse_args()
 
 
@@ -114,6 +117,70 @@ def measured_traffic(kernel):
     return None, None
 
 
+def run_extract(args, world, rank, device):
+    """Forward-only extraction (scmomer.py:96-113): binning, frozen Performer encoder with the per-gene conv head,
+    projection to 128, normalisation, student encoder, to_out.  Cells are sharded contiguously over the ranks; there
+    is no collective.  One step = one batch of args.batch cells (24 by default: one full round of workgroups)."""
+    import types
+    import torch.distributed as dist
+    import scmomer_amd as S
+    from scmomer_amd import dist as sdist
+    from scmomer_amd import ops
+    batch = args.batch if args.batch != BATCH else 24
+    torch.manual_seed(2024)
+    cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+    model = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(N_GENES, 128))
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        model.rna_model.model.pos_emb.emb.weight[:N_GENES] = torch.randn((N_GENES, 200), generator=gen, dtype=torch.float64)
+    model = model.to(device).eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    gen = torch.Generator().manual_seed(100 + rank)
+    cells = [((torch.rand((batch, N_GENES), generator=gen) < 0.15) *
+              torch.distributions.Gamma(2.0, 1 / 1.2).sample((batch, N_GENES))).float().to(device) for _ in range(2)]
+    with torch.no_grad():
+        for i in range(max(args.warmup, 1)):
+            out = model.get_cell_embedding(cells[i % 2])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = model.get_cell_embedding(cells[i % 2])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = sdist.max_over_ranks(time.perf_counter() - t0, device)
+        ops.trace_collect()
+        ops.trace_enable("all")
+        model.get_cell_embedding(cells[0])
+        torch.cuda.synchronize()
+        ops.trace_enable(None)
+        trace = ops.trace_collect()
+    if rank == 0:
+        value = world * batch * args.steps / dt
+        dominant = max(trace, key=lambda k: trace[k][0])
+        ms, fl, cnt, by = trace[dominant]
+        gbs = by / (ms * 1e-3) / 1e9
+        kernels = {k: {"ms_per_step": round(m_, 4), "launches_per_step": c_, "gbs": round(b_ / (m_ * 1e-3) / 1e9, 1)}
+                   for k, (m_, f_, c_, b_) in sorted(trace.items(), key=lambda kv: -kv[1][0])}
+        print(json.dumps({
+            "metric": "cells/sec, Performer RNA encoder forward (cell-embedding extraction, 16.9k genes)",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "scMomer.get_cell_embedding, RNA-only configuration, frozen encoder",
+                       "cells_per_gpu_per_step": batch, "gene_tokens": N_GENES, "depth": 6, "dim": 200, "heads": 10,
+                       "nb_features": 266, "parallelism": f"dp{world}"},
+            "embedding_norm": float(out.float().norm(dim=-1).mean().item()),
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms / cnt,
+                         "whole_step_frac_of_mfma_peak": value / world * 307.52e9 / 1e12 / PEAK_BF16_TFLOPS},
+            "cpu_baseline": None, "kernels": kernels}))
+
+
 def _say(msg):
     if os.environ.get("SCM_BENCH_VERBOSE") == "1":
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -138,6 +205,11 @@ def main():
                                 world_size=world, rank=rank)
 
     _say("process group up")
+    if args.mode == "extract":
+        run_extract(args, world, rank, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from scmomer_amd import dist as sdist
     from scmomer_amd import ops, s1, train
     torch.manual_seed(2024 + rank)

@@ -171,14 +171,6 @@ int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W, i
   if (epi == SCM_EPI_GELU_DUAL) SCM_REQ(out1 && ldo1 >= N, "scm_gemm_nt: GELU_DUAL needs out1");
   if (epi == SCM_EPI_DGELU) SCM_REQ(pre && ldp >= N, "scm_gemm_nt: DGELU needs pre");
   if (resid) SCM_REQ(ldr >= N, "scm_gemm_nt: ldr < N");
-  {  // the kernels address every matrix through 32-bit byte offsets (buffer resources): extents must stay below 4 GiB
-    const int64_t lim = (int64_t)1 << 32;
-    const int64_t out_es = (epi == SCM_EPI_F32 || epi == SCM_EPI_F32_BIAS_RES) ? 4 : 2;
-    SCM_REQ(((int64_t)(M - 1) * lda + K) * (a_f32 ? 4 : 2) < lim && ((int64_t)(N - 1) * ldw + K) * 2 < lim &&
-                ((int64_t)(M - 1) * ldo0 + N) * out_es < lim && (!out1 || ((int64_t)(M - 1) * ldo1 + N) * 2 < lim) &&
-                (!resid || ((int64_t)(M - 1) * ldr + N) * 4 < lim) && (!pre || ((int64_t)(M - 1) * ldp + N) * 2 < lim),
-            "scm_gemm_nt: a matrix extends beyond 4 GiB; split the rows (M=%d)", M);
-  }
   GemmEpi e{out0, (long)ldo0, out1, (long)ldo1, bias, resid, (long)ldr, (const bf16*)pre, (long)ldp};
   SCM_HIP(gemm_nt(epi, a_f32, A, lda, W, ldw, M, N, K, e, (hipStream_t)stream), "scm_gemm_nt");
   return 0;
@@ -193,8 +185,6 @@ int scm_wgrad(const void* Pm, int64_t ldp, const void* Qm, int64_t ldq, int q_f3
           "scm_wgrad: need P%%8==0, Q<=200, Q%%8==0 (P=%d Q=%d)", P, Q);
   SCM_REQ(ldp % 8 == 0 && ldp >= P && ldq >= Q && ldq % 8 == 0 && aligned16(Pm) && aligned16(Qm),
           "scm_wgrad: bad leading dimension or alignment");
-  SCM_REQ(((T - 1) * ldp + P) * 2 < ((int64_t)1 << 32) && ((T - 1) * ldq + Q) * (q_f32 ? 4 : 2) < ((int64_t)1 << 32),
-          "scm_wgrad: an operand extends beyond 4 GiB; split the rows");
   hipStream_t s = (hipStream_t)stream;
   SCM_HIP(wgrad(Pm, ldp, Qm, ldq, q_f32, bias_grad ? 1 : 0, (int)T, P, Q, slices, ws, s), "scm_wgrad");
   SCM_HIP(wgrad_reduce(ws, slices, P, Q, grad, bias_grad, trans, accumulate, s), "scm_wgrad(reduce)");
@@ -209,10 +199,20 @@ int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan) {
   const int bh = B * H;
   const int cus = 256;
   plan->B = B; plan->H = H; plan->N = N;
-  // output pass: one 8-wave workgroup per CU (LDS bound) -> at most one round of workgroups
-  plan->apply_chunks = clampi(cus / bh, 1, (N + 31) / 32);
-  // context pass: 9-wave workgroups, one resident per CU (register bound): one round; partial records cost 75 KB each
-  plan->ctx_chunks = clampi(cus / bh, 1, (N + 63) / 64);
+  // Both passes run one workgroup per CU at a time (LDS / register bound), so the launch is a whole number of
+  // rounds of 256 workgroups: pick the number of token chunks per (b,h) so that the last round is nearly full.
+  // Few, long chunks are preferred (every workgroup first loads 74 KB of images; every context chunk costs a
+  // 75 KB partial record): start from one round and add chunks only while the rounds are under 90 % full.
+  auto pick = [&](int max_chunks) {
+    int c = clampi(cus / bh, 1, max_chunks);
+    auto fill = [&](int cc) { const double r = (double)bh * cc / cus; return r / (double)(long)(r + 0.999999); };
+    if (fill(c) < 0.9)
+      for (int cc = c; cc <= 4 * c + 4 && cc <= max_chunks; ++cc)
+        if (fill(cc) >= 0.93) { c = cc; break; }
+    return c;
+  };
+  plan->apply_chunks = pick((N + 31) / 32);
+  plan->ctx_chunks = pick((N + 63) / 64);
   plan->kmax_chunks = NFT * plan->ctx_chunks;   // one key-stabiliser partial per (chunk, wave) of the context pass
   return 0;
 }

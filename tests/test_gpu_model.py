@@ -192,7 +192,7 @@ def test_full_size_forward_vs_oracle():
 def test_extraction_batch_of_24_cells_full_length():
     """a large no-grad batch at the full gene count (one chunk per (cell, head) in every attention pass): the first
     cell, run inside the batch, agrees with the CPU oracle of the same batch's first cells within the bf16
-    tolerance, the batch is reproducible, and a batch beyond the addressing limit is refused with a clear message"""
+    tolerance, and the batch is reproducible"""
     n, depth = 16906, 2
     p = O.make_params(77, depth=depth, max_seq_len=n)
     cells = O.synthetic_cells(77, 24, n)
@@ -209,8 +209,6 @@ def test_extraction_batch_of_24_cells_full_length():
     assert relmax(pair, ref) < TOL_MAX and rell2(pair, ref) < TOL_L2
     # inside the larger batch the key stabiliser is the max over 24 cells instead of 2: a tiny, bounded difference
     assert relmax(out[:2], ref) < 2 * TOL_MAX
-    with pytest.raises(ValueError, match="4 GiB"):
-        m(torch.zeros((70, n), dtype=torch.int64, device=DEV))
 
 
 def test_scmomer_cell_embedding_matches_reference_fixture(golden_dir):
