@@ -99,8 +99,15 @@ def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group: Op
     """Replicate rank `src`'s parameters and buffers (what DDP does at construction)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    gloo = dist.get_backend(group) == "gloo"
     for p in params:
-        dist.broadcast(p.data if isinstance(p, torch.nn.Parameter) else p, src=src, group=group)
+        t = p.data if isinstance(p, torch.nn.Parameter) else p
+        if gloo and t.is_cuda:          # CPU-only backend: stage device tensors through host memory
+            host = t.cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=src, group=group)
 
 
 def max_over_ranks(seconds: float, device) -> float:
