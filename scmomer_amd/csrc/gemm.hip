@@ -303,8 +303,12 @@ constexpr int SK_WBYTES = 4 * 64 * 128;   // one W chunk: 4 k-blocks of [64 rows
 // Accumulator register r of tile t on lane-half h then holds column 16(r>>2) + 8h + 4t + (r&3).
 SCM_DEV int sk_panel_row(int c) { return 32 * ((c >> 2) & 1) + 8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3); }
 
+// Loads that the epilogue waits for must not be issued after stores: memory operations retire in issue order, so
+// such a load would wait for the stores of the previous item.  Hence the bias vector is copied to LDS once, and the
+// pre-activation rows of the GELU' epilogue are fetched one item ahead, before the current item's stores (16 more
+// live registers: that variant runs 2 workgroups per CU instead of 3).
 template <bool A_F32, int EPI>
-__global__ __launch_bounds__(256, 3) void gemm_skinny_kernel(const void* __restrict__ Ap, long lda,
+__global__ __launch_bounds__(256, EPI == EPI_DGELU ? 2 : 3) void gemm_skinny_kernel(const void* __restrict__ Ap, long lda,
                                                              const bf16* __restrict__ W, long ldw, int M, int N,
                                                              int K, GemmEpi e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,6 +334,9 @@ __global__ __launch_bounds__(256, 3) void gemm_skinny_kernel(const void* __restr
   const brsrc rB = make_rsrc(has_bias ? (const void*)e.bias : (const void*)W, has_bias ? (uint32_t)N * 4 : 0u);
 
   char* Ws = smem;
+  float* bias_s = (float*)(smem + SK_WBYTES);      // [64 * nchunks] f32 (zeros where there is no bias)
+  if (EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS)
+    for (int i = tid; i < 16 * nchunks; i += 256) *(u32x4*)(bias_s + 4 * i) = buf_load16(rB, (uint32_t)i * 16);
   int roff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) roff[i] = img_off(l & 31, 16 * i + 8 * half);
@@ -387,6 +394,18 @@ __global__ __launch_bounds__(256, 3) void gemm_skinny_kernel(const void* __restr
     }
   };
   load_a(it_lo / nchunks);
+  // pre-activation rows of an item (GELU' epilogue): lane = its token, 4 groups of 8 columns
+  u32x4 pv[4];
+  auto load_pre = [&](int item, u32x4 (&dst)[4]) {
+    const int tl = item / nchunks, cc = item - tl * nchunks;
+    const long r = (long)tl * G_BM + 32 * w + (l & 31);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 64 * cc + 8 * half + 16 * g;
+      dst[g] = buf_load16(rP, (item < it_hi && r < M && col < N) ? ((uint32_t)(r * e.ldp) + (uint32_t)col) * 2 : BUF_OOB);
+    }
+  };
+  if (EPI == EPI_DGELU) load_pre(it_lo, pv);
   for (int it = it_lo; it < it_hi; ++it) {
     const int tile = it / nchunks, c = it - tile * nchunks;
     const long orow = row;          // the epilogue below still belongs to this item's tile
@@ -410,18 +429,15 @@ __global__ __launch_bounds__(256, 3) void gemm_skinny_kernel(const void* __restr
       oo[g] = (orow < M && col < N) ? (uint32_t)col : BUF_OOB;   // column part; row part added per tensor
       bias_off[g] = (uint32_t)col * 4;
     }
-    u32x4 pv[4];
-    if (EPI == EPI_DGELU) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        pv[g] = buf_load16(rP, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldp) + oo[g]) * 2);
-    }
+    u32x4 npv[4];
+    if (EPI == EPI_DGELU) load_pre(it + 1, npv);   // ahead of this item's stores
+    u32x4 ov[4], gv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float v[8] = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3],
                     acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
       if (EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) {   // a null bias reads zeros
-        const f32x4 b0 = as_f32x4(buf_load16(rB, bias_off[g])), b1 = as_f32x4(buf_load16(rB, bias_off[g] + 16));
+        const f32x4 b0 = *(const f32x4*)(bias_s + (bias_off[g] >> 2)), b1 = *(const f32x4*)(bias_s + (bias_off[g] >> 2) + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
       }
@@ -434,13 +450,26 @@ __global__ __launch_bounds__(256, 3) void gemm_skinny_kernel(const void* __restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
       }
-      buf_store16(rO0, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo0) + oo[g]) * 2, as_u32x4(o));
+      ov[g] = as_u32x4(o);
       if (EPI == EPI_GELU_DUAL) {
         bf16x8 gl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) gl[j] = (bf16)gelu_erf(v[j]);
-        buf_store16(rO1, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo1) + oo[g]) * 2, as_u32x4(gl));
+        gv[g] = as_u32x4(gl);
       }
+    }
+    // the four 32-byte pieces of each output line are stored back to back, one tensor after the other
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      buf_store16(rO0, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo0) + oo[g]) * 2, ov[g]);
+    if (EPI == EPI_GELU_DUAL) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        buf_store16(rO1, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo1) + oo[g]) * 2, gv[g]);
+    }
+    if (EPI == EPI_DGELU) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pv[g] = npv[g];
     }
     __syncthreads();                       // next item's chunk visible
   }
@@ -796,7 +825,10 @@ static hipError_t launch_skinny(const void* A, long lda, const bf16* W, long ldw
   long grid = force > 0 ? force : 768;
   if (grid > total) grid = total;
   Traced tr(K_GEMM_SKINNY + EPI, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
-  hipLaunchKernelGGL((gemm_skinny_kernel<A_F32, EPI>), dim3((unsigned)grid), dim3(256), SK_WBYTES, s, A, lda, W, ldw,
+  // one round of resident workgroups: 3 per CU, 2 for the GELU' variant (see the kernel)
+  if (EPI == EPI_DGELU && force <= 0 && grid > 512) grid = 512;
+  const size_t lds = SK_WBYTES + (size_t)((N + 63) / 64) * 64 * sizeof(float);
+  hipLaunchKernelGGL((gemm_skinny_kernel<A_F32, EPI>), dim3((unsigned)grid), dim3(256), lds, s, A, lda, W, ldw,
                      M, N, K, e);
   return hipGetLastError();
 }

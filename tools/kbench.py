@@ -71,3 +71,25 @@ if not filt or "favor" in filt:
     torch.cuda.synchronize(); ops.trace_enable(None)
     for name, (ms, fl, cnt, by) in sorted(ops.trace_collect().items(), key=lambda kv: -kv[1][0]):
         print(f"{name:32s} {ms / cnt * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  {by / (ms * 1e-3) / 1e12:5.2f} TB/s")
+
+# ---- weight-gradient sweep: P width and token slices (filter "wsweep"), kernel time without the slab reduction
+if filt == "wsweep":
+    from scmomer_amd._lib import lib, check
+    for P in (128, 256, 640, 800, 1920):
+        pm = rnd(T, P); qm = rnd(T, 200)
+        g = torch.zeros(P, 200, device=dev)
+        ptiles = (P + 127) // 128
+        for slices in sorted({max(1, 128 // ptiles), max(1, 256 // ptiles), max(1, 512 // ptiles), max(1, 768 // ptiles)}):
+            ws = torch.empty(lib.scm_wgrad_ws_floats(P, slices), dtype=f32, device=dev)
+            def call():
+                check(lib.scm_wgrad(pm.data_ptr(), P, qm.data_ptr(), 200, 0, T, P, 200, slices, ws.data_ptr(), g.data_ptr(),
+                                    None, 0, 0, torch.cuda.current_stream().cuda_stream), "wgrad")
+            for _ in range(3): call()
+            torch.cuda.synchronize(); ops.trace_collect(); ops.trace_enable("all")
+            for _ in range(10): call()
+            torch.cuda.synchronize(); ops.trace_enable(None)
+            tr = ops.trace_collect()
+            by = T * (P + 200) * 2
+            wg, rd = tr["wgrad"][0] / 10, tr["wgrad_reduce"][0] / 10
+            print(f"P {P:5d} slices {slices:4d} WGs {ptiles * slices:4d}  wgrad {wg * 1e3:7.1f} us ({by / wg / 1e9:5.2f} TB/s)  "
+                  f"reduce {rd * 1e3:6.1f} us  slab {ws.numel() * 4 / 1e6:6.1f} MB")
