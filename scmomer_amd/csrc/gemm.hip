@@ -27,7 +27,7 @@ constexpr int G_SP = 68;   // floats per staged epilogue row (64 + 4: rows 16-by
 // then read back row-wise so that every lane handles 8 consecutive columns of one row: 16-byte (bf16) /
 // 32-byte (f32) global stores, 128..256 contiguous bytes per row; the bias / residual / pre-activation
 // operands are read with the same coalesced shape.
-template <int EPI>
+template <int EPI, bool FOLDED = false>   // FOLDED: bias and residual already sit in the accumulators
 SCM_DEV void epilogue_pair(float* stage, const f32x16& acc0, const f32x16& acc1, bool two, long row0, int col0,
                            int M, int N, const GemmEpi& e) {
   const int l = lane_id(), half = l >> 5;
@@ -43,7 +43,7 @@ SCM_DEV void epilogue_pair(float* stage, const f32x16& acc0, const f32x16& acc1,
   float bias[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bias[j] = 0.f;
-  if ((EPI == EPI_F32_BIAS_RES || EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) && e.bias && col_ok) {
+  if (!FOLDED && (EPI == EPI_F32_BIAS_RES || EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) && e.bias && col_ok) {
     const f32x4 b0 = *(const f32x4*)(e.bias + col), b1 = *(const f32x4*)(e.bias + col + 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bias[j] = b0[j]; bias[4 + j] = b1[j]; }
@@ -64,7 +64,7 @@ SCM_DEV void epilogue_pair(float* stage, const f32x16& acc0, const f32x16& acc1,
       for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
       *(bf16x8*)((bf16*)e.out0 + row * e.ldo0 + col) = o;
     } else if (EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES) {
-      if (EPI == EPI_F32_BIAS_RES && e.resid) {
+      if (!FOLDED && EPI == EPI_F32_BIAS_RES && e.resid) {
         const f32x4 r0 = *(const f32x4*)(e.resid + row * e.ldr + col);
         const f32x4 r1 = *(const f32x4*)(e.resid + row * e.ldr + col + 4);
 #pragma unroll
@@ -263,6 +263,25 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
   for (int i = 0; i < 4; ++i) roff[i] = img_off(l & 31, 16 * i + 8 * (l >> 5));
 
   issue(0, 0);
+  if (EPI == EPI_F32_BIAS_RES) {
+    // Y = A W^T + bias + residual: the accumulators START at bias + residual (lane = column, registers = rows; a
+    // load instruction covers two rows x 128 contiguous bytes), fetched while the first k stages are in flight.
+    // The epilogue then has no loads: a load issued there would wait for the stores of the previous column pair.
+    const brsrc rR = make_rsrc(e.resid ? (const void*)e.resid : (const void*)W,
+                               e.resid ? (uint32_t)(((long)(M - 1) * e.ldr + N) * 4) : 0u);
+    const brsrc rBias = make_rsrc(e.bias ? (const void*)e.bias : (const void*)W, e.bias ? (uint32_t)N * 4 : 0u);
+#pragma unroll
+    for (int t = 0; t < GD_NT; ++t) {
+      const int col = 32 * t + (l & 31);
+      const float bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rBias, col < N ? col * 4 : (int)BUF_OOB, 0, 0));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long row = r0 + 32 * w + acc_row(r, l >> 5);
+        const uint32_t off = (row < r1 && col < N) ? (uint32_t)(row * e.ldr + col) * 4 : BUF_OOB;
+        acc[t][r] = bv + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, (int)off, 0, 0));
+      }
+    }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<0>();                       // this wave's copies of stage kt have landed
     __builtin_amdgcn_s_barrier();          // everyone's have; everyone is done reading the other buffer
@@ -281,8 +300,8 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
   const int mlim = (int)r1;                 // rows from r1 on belong to the next workgroup
 #pragma unroll
   for (int tp = 0; tp < (GD_NT + 1) / 2; ++tp)
-    epilogue_pair<EPI>(stage, acc[2 * tp], acc[(2 * tp + 1 < GD_NT) ? 2 * tp + 1 : 2 * tp], 2 * tp + 1 < GD_NT,
-                       r0 + 32 * w, 64 * tp, mlim, N, e);
+    epilogue_pair<EPI, EPI == EPI_F32_BIAS_RES>(stage, acc[2 * tp], acc[(2 * tp + 1 < GD_NT) ? 2 * tp + 1 : 2 * tp],
+                                                2 * tp + 1 < GD_NT, r0 + 32 * w, 64 * tp, mlim, N, e);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -844,7 +863,8 @@ static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, 
   if (fits && K > 16 * (SK_KS - 1) && K <= 16 * SK_KS && N >= 256 &&
       (EPI == EPI_BF16 || EPI == EPI_BF16_BIAS || EPI == EPI_GELU_DUAL || EPI == EPI_DGELU))
     return launch_skinny<A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
-  if (!A_F32 && N <= 224 && K >= 128 && (long)M * lda * 2 < lim && (long)N * ldw * 2 < lim) {
+  if (!A_F32 && N <= 224 && K >= 128 && (long)M * lda * 2 < lim && (long)N * ldw * 2 < lim &&
+      (EPI != EPI_F32_BIAS_RES || !e.resid || (long)M * e.ldr * 4 < lim)) {
     const size_t lds = (size_t)2 * GD_STAGE;
     static bool attr = false;
     if (!attr) {
