@@ -539,14 +539,25 @@ SCM_DEV void stage_rows(float* stage, const f32x16 (&y)[2], float scale, const f
 // coalesced write-back of a staged [32][64] f32 tile as bf16; optional rank-1 correction
 // out[row][d] = stage[row][d] + stage[row][64] * corr_scale * xrow[d]
 // and, with omg != null, + stage[row][65] * Omega[(int)stage[row][66]][d] (Omega from its LDS image)
-SCM_DEV void store_rows(const float* stage, brsrc ro, long osn, bool with_x, brsrc rxx, long xsn, float corr_scale,
+// The x rows of a tile in the write-back layout (row 8i + (l>>3), columns 8(l&7)..+7), for the correction term of
+// store_rows.  Fetched BEFORE the tile's first store: a load issued after a store waits for that store to retire.
+SCM_DEV void load_x_rows(bf16x8 (&xr)[4], brsrc rxx, long xsn, int n0, int n_hi) {
+  const int l = lane_id();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + 8 * i + (l >> 3);
+    xr[i] = as_bf16x8(buf_load16(rxx, n < n_hi ? (uint32_t)((long)n * xsn + 8 * (l & 7)) * 2 : BUF_OOB));
+  }
+}
+
+SCM_DEV void store_rows(const float* stage, brsrc ro, long osn, const bf16x8* xr /*4 rows or null*/, float corr_scale,
                         int n0, int n_hi, const char* omg = nullptr, const float* colbias = nullptr) {
   const int l = lane_id();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 8 * i + (l >> 3), ch = l & 7;
     const int n = n0 + row;
-    const bool ok = n < n_hi;     // rows past the chunk: loads return 0, stores are dropped (no branches)
+    const bool ok = n < n_hi;     // rows past the chunk: stores are dropped (no branches)
     const f32x4 a = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch);
     const f32x4 b = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch + 4);
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -554,11 +565,10 @@ SCM_DEV void store_rows(const float* stage, brsrc ro, long osn, bool with_x, brs
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += colbias[8 * ch + j];
     }
-    if (with_x) {
+    if (xr) {
       const float cs = stage[row * STAGE_PITCH + 64] * corr_scale;
-      const bf16x8 xv = as_bf16x8(buf_load16(rxx, ok ? (uint32_t)((long)n * xsn + 8 * ch) * 2 : BUF_OOB));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += cs * (float)xv[j];
+      for (int j = 0; j < 8; ++j) v[j] += cs * (float)xr[i][j];
     }
     if (omg) {
       const float os = stage[row * STAGE_PITCH + 65];
@@ -691,8 +701,8 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
       stage_rows(stage, Y, inv, nullptr, 0.f);
       __builtin_amdgcn_wave_barrier();
-      store_rows(stage, ro1, a.out1.sn, false, rx, 0, 0.f, n0, n_hi);
-      store_rows(stage, ro0, a.out0.sn, false, rx, 0, 0.f, n0, n_hi, nullptr, sm);
+      store_rows(stage, ro1, a.out1.sn, nullptr, 0.f, n0, n_hi);
+      store_rows(stage, ro0, a.out0.sn, nullptr, 0.f, n0, n_hi, nullptr, sm);
       __builtin_amdgcn_wave_barrier();
       if (valid && l < 32) { a.rowmax_out[srow + n] = mx; a.den_out[srow + n] = den; }
     }
@@ -767,6 +777,8 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       const float ddiag = -xhalf_sum(rs);
       const float stabc = -xhalf_sum(rsm);
       jstar = min(jstar, __shfl_xor(jstar, 32));
+      bf16x8 xr[4];
+      load_x_rows(xr, rx, a.x.sn, n0, n_hi);
       fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
       stage_rows(stage, Y, CNORM, nullptr, 0.f);
       if (l < 32) {
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
         ((int*)stage)[(l & 31) * STAGE_PITCH + 66] = (jstar < NF) ? jstar : 0;
       }
       __builtin_amdgcn_wave_barrier();
-      store_rows(stage, ro0, a.out0.sn, true, rx, a.x.sn, 2.f * HALF_C2, n0, n_hi, omg);
+      store_rows(stage, ro0, a.out0.sn, xr, 2.f * HALF_C2, n0, n_hi, omg);
       __builtin_amdgcn_wave_barrier();
       if (valid && l < 32) a.dden_out[srow + n] = dden;
     }
@@ -829,16 +841,18 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       tile(NFT - 1, std::true_type{});
       const float ddiag = -xhalf_sum(rs);
       if (valid && l < 32) ksum -= ddiag;
+      bf16x8 xr[4];
+      load_x_rows(xr, rx, a.x.sn, n0, n_hi);
       fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
-      // dv = E dC + eps * colsum(dC)
-      stage_rows(stage, Yv, 1.f, sm, KEPS);
-      __builtin_amdgcn_wave_barrier();
-      store_rows(stage, ro1, a.out1.sn, false, rx, 0, 0.f, n0, n_hi);
-      __builtin_amdgcn_wave_barrier();
+      // dk first (it consumes the x rows), then dv = E dC + eps * colsum(dC)
       stage_rows(stage, Yk, CNORM, nullptr, 0.f);
       if (l < 32) stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
       __builtin_amdgcn_wave_barrier();
-      store_rows(stage, ro0, a.out0.sn, true, rx, a.x.sn, 2.f * HALF_C2, n0, n_hi);
+      store_rows(stage, ro0, a.out0.sn, xr, 2.f * HALF_C2, n0, n_hi);
+      __builtin_amdgcn_wave_barrier();
+      stage_rows(stage, Yv, 1.f, sm, KEPS);
+      __builtin_amdgcn_wave_barrier();
+      store_rows(stage, ro1, a.out1.sn, nullptr, 0.f, n0, n_hi);
       __builtin_amdgcn_wave_barrier();
     }
     // rotate: the prefetched fragments become the current ones
