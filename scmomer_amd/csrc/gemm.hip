@@ -324,10 +324,11 @@ SCM_DEV int sk_panel_row(int c) { return 32 * ((c >> 2) & 1) + 8 * (c >> 4) + 4 
 
 // Loads that the epilogue waits for must not be issued after stores: memory operations retire in issue order, so
 // such a load would wait for the stores of the previous item.  Hence the bias vector is copied to LDS once, and the
-// pre-activation rows of the GELU' epilogue are fetched one item ahead, before the current item's stores (16 more
-// live registers: that variant runs 2 workgroups per CU instead of 3).
+// pre-activation rows of the GELU' epilogue are fetched one item ahead, before the current item's stores.
+// The W panel is double-buffered in LDS (two workgroups per CU; a third one was measured to add nothing): the next
+// item's chunk is written to the other buffer while this item is multiplied, one barrier per item.
 template <bool A_F32, int EPI>
-__global__ __launch_bounds__(256, EPI == EPI_DGELU ? 2 : 3) void gemm_skinny_kernel(const void* __restrict__ Ap, long lda,
+__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const void* __restrict__ Ap, long lda,
                                                              const bf16* __restrict__ W, long ldw, int M, int N,
                                                              int K, GemmEpi e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -352,8 +353,7 @@ __global__ __launch_bounds__(256, EPI == EPI_DGELU ? 2 : 3) void gemm_skinny_ker
   const bool has_bias = (EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS) && e.bias != nullptr;
   const brsrc rB = make_rsrc(has_bias ? (const void*)e.bias : (const void*)W, has_bias ? (uint32_t)N * 4 : 0u);
 
-  char* Ws = smem;
-  float* bias_s = (float*)(smem + SK_WBYTES);      // [64 * nchunks] f32 (zeros where there is no bias)
+  float* bias_s = (float*)(smem + 2 * SK_WBYTES);  // [64 * nchunks] f32 (zeros where there is no bias)
   if (EPI == EPI_GELU_DUAL || EPI == EPI_BF16_BIAS)
     for (int i = tid; i < 16 * nchunks; i += 256) *(u32x4*)(bias_s + 4 * i) = buf_load16(rB, (uint32_t)i * 16);
   int roff[4];
@@ -374,18 +374,19 @@ __global__ __launch_bounds__(256, EPI == EPI_DGELU ? 2 : 3) void gemm_skinny_ker
     for (int j = 0; j < 6; ++j) wst[j] = buf_load16(rW, base + 64 * j);        // k chunks q+4j <= 23 < kc
     wst[6] = buf_load16(rW, (q + 24 < kc) ? base + 64 * 6 : BUF_OOB);
   };
-  auto store_w = [&]() {   // chunks >= kc carry zeros: the panel's k tail is cleared on every refill
+  auto store_w = [&](char* Wd) {   // chunks >= kc carry zeros: the panel's k tail is cleared on every refill
 #pragma unroll
-    for (int j = 0; j < 7; ++j) *(u32x4*)(Ws + (j >> 1) * (64 * 128) + ((j & 1) ? wdst1 : wdst0)) = wst[j];
+    for (int j = 0; j < 7; ++j) *(u32x4*)(Wd + (j >> 1) * (64 * 128) + ((j & 1) ? wdst1 : wdst0)) = wst[j];
   };
-  {  // k chunks 28..31 of the last k-block are never written by store_w: clear them once
-    *(u32x4*)(Ws + 3 * (64 * 128) + img_off(wr, 8 * (4 + q))) = u32x4{0, 0, 0, 0};
-  }
+  // k chunks 28..31 of the last k-block are never written by store_w: clear them once, in both buffers
+  *(u32x4*)(smem + 3 * (64 * 128) + img_off(wr, 8 * (4 + q))) = u32x4{0, 0, 0, 0};
+  *(u32x4*)(smem + SK_WBYTES + 3 * (64 * 128) + img_off(wr, 8 * (4 + q))) = u32x4{0, 0, 0, 0};
 
-  // Software pipeline over the items: while item i is multiplied, the W chunk of item i+1 sits in registers and
-  // the loads of item i+2's chunk are issued before the epilogue's stores.
+  // Software pipeline over the items: while item i is multiplied from one LDS buffer, the W chunk of item i+1
+  // (in registers since the previous iteration) is written to the other buffer and the loads of item i+2's chunk
+  // are issued, all before the epilogue's stores.
   load_w(it_lo);
-  store_w();
+  store_w(smem);
   __syncthreads();
   load_w(it_lo + 1);
 
@@ -428,6 +429,9 @@ __global__ __launch_bounds__(256, EPI == EPI_DGELU ? 2 : 3) void gemm_skinny_ker
   for (int it = it_lo; it < it_hi; ++it) {
     const int tile = it / nchunks, c = it - tile * nchunks;
     const long orow = row;          // the epilogue below still belongs to this item's tile
+    const char* Ws = smem + ((it - it_lo) & 1) * SK_WBYTES;
+    store_w(smem + ((it - it_lo + 1) & 1) * SK_WBYTES);   // its last readers passed the barrier of the previous item
+    load_w(it + 2);
     f32x16 acc0 = zero16(), acc1 = zero16();
 #pragma unroll
     for (int ks = 0; ks < SK_KS; ++ks) {   // 26 independent LDS reads feeding 26 MFMAs
@@ -436,9 +440,6 @@ __global__ __launch_bounds__(256, EPI == EPI_DGELU ? 2 : 3) void gemm_skinny_ker
       acc1 = mfma32(*(const bf16x8*)(blk + 4096 + roff[ks & 3]), af[ks], acc1);
     }
     if (c + 1 == nchunks && it + 1 < it_hi) load_a(tile + 1);
-    __syncthreads();                       // every wave is done reading this item's W panel
-    store_w();                             // next item's chunk (loaded one iteration ago)
-    load_w(it + 2);
     // ---- epilogue on registers: lane = token `orow`, group g = columns col .. col+7; straight-line
     const int colb = 64 * c + 8 * half;
     uint32_t oo[4], bias_off[4];
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256, EPI == EPI_DGELU ? 2 : 3) void gemm_skinny_ker
 #pragma unroll
       for (int g = 0; g < 4; ++g) pv[g] = npv[g];
     }
-    __syncthreads();                       // next item's chunk visible
+    __syncthreads();                       // next item's chunk visible; this item's buffer is free
   }
 }
 
@@ -839,14 +840,17 @@ template <bool A_F32, int EPI>
 static hipError_t launch_skinny(const void* A, long lda, const bf16* W, long ldw, int M, int N, int K, GemmEpi e,
                                 hipStream_t s) {
   const long total = (long)((M + G_BM - 1) / G_BM) * ((N + 63) / 64);
-  // 3 workgroups per CU are resident (register bound): one full wave of them, each with an equal item range
+  // 2 workgroups per CU are resident (LDS: two W panels each): one full round of them, each with an equal item range
   static const int force = getenv("SCM_SK_GRID") ? atoi(getenv("SCM_SK_GRID")) : 0;
-  long grid = force > 0 ? force : 768;
+  long grid = force > 0 ? force : 512;
   if (grid > total) grid = total;
   Traced tr(K_GEMM_SKINNY + EPI, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
-  // one round of resident workgroups: 3 per CU, 2 for the GELU' variant (see the kernel)
-  if (EPI == EPI_DGELU && force <= 0 && grid > 512) grid = 512;
-  const size_t lds = SK_WBYTES + (size_t)((N + 63) / 64) * 64 * sizeof(float);
+  const size_t lds = 2 * SK_WBYTES + (size_t)((N + 63) / 64) * 64 * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<A_F32, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
   hipLaunchKernelGGL((gemm_skinny_kernel<A_F32, EPI>), dim3((unsigned)grid), dim3(256), lds, s, A, lda, W, ldw,
                      M, N, K, e);
   return hipGetLastError();
