@@ -110,9 +110,7 @@ def measured_traffic(kernel):
             f = re.search(r"FETCH_SIZE=([0-9.e+]+)", lines[i + 1])
             w = re.search(r"WRITE_SIZE=([0-9.e+]+)", lines[i + 1])
             if f and w:
-                # the output/backward attention passes first touch every row with 16-byte-per-sector copies (their
-                # prefetch), which FETCH_SIZE counts at full size, and then hit L2: no doubling for them
-                fetch_scale = 1.0 if sym.startswith("favor_apply_kernel") else 2.0
+                fetch_scale = 2.0
                 return (fetch_scale * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.basename(files[-1])
     return None, None
 
