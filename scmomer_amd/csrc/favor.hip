@@ -211,6 +211,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     for (int ks = 0; ks < 4; ++ks) omf[ks] = *(const bf16x8*)(orow + 16 * ks + 8 * half);
   }
   const bool lane_feat_valid = (32 * w + (l & 31)) < NF;
+  const bool pad_wave = __builtin_amdgcn_readfirstlane(w) == NFT - 1;   // wave-uniform
   const LaneOffs lo = lane_offs();
   // b_m / c for this lane's feature: the score accumulator starts there instead of at zero (MODE 0)
   float sinit = 0.f;
@@ -309,18 +310,22 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
         lane_pos = up ? 2 * it + sub : lane_pos;
       }
       f32x16 e;
+      auto features = [&](auto pad_c) {   // only the last wave owns padding features: the select is compiled out elsewhere
+        constexpr bool PAD = decltype(pad_c)::value;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 o4 = *(const f32x4*)(off + 32 * sub + 8 * g + 4 * half);
-        const f32x4 w4 = *(const f32x4*)(wg + 32 * sub + 8 * g + 4 * half);
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o4 = *(const f32x4*)(off + 32 * sub + 8 * g + 4 * half);
+          const f32x4 w4 = *(const f32x4*)(wg + 32 * sub + 8 * g + 4 * half);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = exp2_fast(s[4 * g + i] * (CNORM * LOG2E) - o4[i]);
-          v = lane_feat_valid ? v : padv;
-          e[4 * g + i] = v;
-          zacc += v * w4[i];
+          for (int i = 0; i < 4; ++i) {
+            float v = exp2_fast(s[4 * g + i] * (CNORM * LOG2E) - o4[i]);
+            if (PAD) v = lane_feat_valid ? v : padv;
+            e[4 * g + i] = v;
+            zacc += v * w4[i];
+          }
         }
-      }
+      };
+      if (MODE == 1 || pad_wave) features(std::true_type{}); else features(std::false_type{});
       // C_w[feature, d] += E^T (32 features x 32 tokens) * y (32 tokens x 64)
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
@@ -334,14 +339,8 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     __syncthreads();
   }
 
-  // partial record
-  float* rec = a.part + ((long)bh * gridDim.x + blockIdx.x) * CTX_PART;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rec[(32 * w + acc_row(r, half)) * DH + 32 * dt + (l & 31)] = cacc[dt][r];
-  const float zt = xhalf_sum(zacc);
-  if (l < 32) rec[NFP * DH + 32 * w + l] = zt;
+  // The arg-max resolution below reads global memory: it comes BEFORE the partial record is stored (a load issued
+  // after the stores would wait for them to retire).
   if (MODE == 0) {
     // wave-level argmax: the max of the raw scores, and the first (token, feature) attaining it.  The sub-tile
     // that holds it is recomputed from global memory with the same MFMA sequence (bit-identical scores).
@@ -378,6 +377,14 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
       a.key_out[slot] = key;
     }
   }
+  // partial record
+  float* rec = a.part + ((long)bh * gridDim.x + blockIdx.x) * CTX_PART;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rec[(32 * w + acc_row(r, half)) * DH + 32 * dt + (l & 31)] = cacc[dt][r];
+  const float zt = xhalf_sum(zacc);
+  if (l < 32) rec[NFP * DH + 32 * w + l] = zt;
 }
 
 // stab (forward keys only, else null): the per-(b,h, chunk, wave) running maxima of the raw key scores, nstab of
