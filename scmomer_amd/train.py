@@ -232,7 +232,8 @@ class S1Trainer:
         logits = self.model(masked)
         loss = self.loss_fn(logits, labels, self.pad_id) / self.grad_acc
         loss.backward()
-        torch._foreach_add_(self.accs, [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params])
+        if self.params:
+            torch._foreach_add_(self.accs, [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params])
         for p in self.params:
             p.grad = None                                    # the next backward stores, it does not add
         return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
@@ -245,7 +246,8 @@ class S1Trainer:
             self.averager.average_()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
         self.optimizer.step()
-        torch._foreach_zero_(self.accs)
+        if self.accs:
+            torch._foreach_zero_(self.accs)
         for p in self.params:
             p.grad = None
         if self._graph is not None:
@@ -280,6 +282,14 @@ class S1Trainer:
         for a, s_ in zip(self.accs, saved):                  # warm-up and recording passes do not count
             a.copy_(s_)
         self._graph, self._graph_shape, self._graph_auto = graph, tuple(data.shape), auto
+
+    def release_graph(self) -> None:
+        """Drop the recorded micro-step (the next micro_step records again) and hand the redraw check back to the
+        model's own forward, e.g. before the model is used outside this driver."""
+        performer = getattr(self.model, "performer", None)
+        if self._graph is not None and performer is not None:
+            performer.auto_check_redraw = self._graph_auto
+        self._graph = self._graph_shape = None
 
     def prepare(self, example: torch.Tensor) -> None:
         """Record the micro-step graph for batches shaped like ``example`` now (otherwise the first micro_step
