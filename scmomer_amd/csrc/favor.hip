@@ -778,7 +778,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           for (int dt = 0; dt < 2; ++dt) Y[dt] = mfma32(tr_frag_at(ob_, lo.tr[sk][dt]), af, Y[dt]);
         }
       };
-#pragma unroll 1
+#pragma unroll 2
       for (int t = 0; t < NFT - 1; ++t) tile(t, std::false_type{});
       tile(NFT - 1, std::true_type{});
       const float ddiag = -xhalf_sum(rs);
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
           }
         }
       };
-#pragma unroll 1
+#pragma unroll 2
       for (int t = 0; t < NFT - 1; ++t) tile(t, std::false_type{});
       tile(NFT - 1, std::true_type{});
       const float ddiag = -xhalf_sum(rs);
