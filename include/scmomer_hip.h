@@ -134,7 +134,8 @@ int scm_head_bwd(const float* dout, const float* denc, const float* out, const f
 /* Per cell (row of tokens [B,N], int64): tokens 0 and pad_id are never maskable; the ceil(f32(count) * mask_prob)
  * maskable positions with the largest rand_pick draws are picked (at most max_masked = ceil(mask_prob * N); equal
  * draws at the boundary: lowest positions first); picked positions with rand_replace < replace_prob become
- * mask_id in masked_input; labels = token at picked positions, pad_id elsewhere.  Draws are f32 in [0,1). */
+ * mask_id in masked_input; labels = token at picked positions, pad_id elsewhere.  Draws are f32 in [0,1).
+ * N <= 20480. */
 int scm_s1_mask(const int64_t* tokens, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,
                 float replace_prob, int max_masked, int64_t pad_id, int64_t mask_id, int64_t* masked_input,
                 int64_t* labels, void* stream);

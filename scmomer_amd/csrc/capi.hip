@@ -300,7 +300,8 @@ int scm_s1_mask(const int64_t* tokens, const float* rand_pick, const float* rand
                 float replace_prob, int max_masked, int64_t pad_id, int64_t mask_id, int64_t* masked_input,
                 int64_t* labels, void* stream) {
   SCM_REQ(tokens && rand_pick && rand_replace && masked_input && labels, "scm_s1_mask: null pointer");
-  SCM_REQ(B > 0 && N > 0 && (int64_t)B * N < (1ll << 31), "scm_s1_mask: bad sizes");
+  SCM_REQ(B > 0 && N > 0 && N <= 20 * 1024 && (int64_t)B * N < (1ll << 31),
+          "scm_s1_mask: need 0 < N <= 20480 (a cell's keys are held in the registers of one workgroup)");
   SCM_REQ(mask_prob >= 0.f && mask_prob <= 1.f && replace_prob >= 0.f && replace_prob <= 1.f && max_masked >= 0,
           "scm_s1_mask: probabilities must be in [0,1]");
   SCM_HIP(s1_mask(tokens, rand_pick, rand_replace, B, N, mask_prob, replace_prob, max_masked, pad_id, mask_id,

@@ -17,6 +17,8 @@ namespace scm {
 // of the values); draws above it are picked, and of the draws equal to it the lowest positions, as many as are
 // still needed.
 // ------------------------------------------------------------------------------------------
+constexpr int S1_PER_THREAD = 20;   // positions per thread held in registers: N <= 20 * 1024
+
 __global__ __launch_bounds__(1024) void s1_mask_kernel(const int64_t* __restrict__ tok,
                                                        const float* __restrict__ rand_pick,
                                                        const float* __restrict__ rand_replace, int N,
@@ -24,19 +26,32 @@ __global__ __launch_bounds__(1024) void s1_mask_kernel(const int64_t* __restrict
                                                        long long pad_id, long long mask_id,
                                                        int64_t* __restrict__ masked, int64_t* __restrict__ labels) {
   __shared__ int hist[256];
-  __shared__ int sh_count, sh_prefix, sh_need, sh_tiebase;
-  __shared__ int wave_cnt[16];
+  __shared__ int sh_count, sh_prefix, sh_need;
+  __shared__ int tie_cnt[S1_PER_THREAD * 16];
   const int tid = threadIdx.x;
   const long base = (long)blockIdx.x * N;
   const int64_t* t = tok + base;
   const float* rp = rand_pick + base;
   const float* rr = rand_replace + base;
 
+  // The cell is read ONCE: every thread keeps the keys of its positions (tid, tid + 1024, ...) in registers;
+  // key 0xFFFFFFFF marks "not maskable" (draws are in [0,1): their bit patterns stay below 0x3F800000).
+  unsigned keys[S1_PER_THREAD];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < S1_PER_THREAD; ++j) {
+    const int i = tid + 1024 * j;
+    unsigned k = 0xFFFFFFFFu;
+    if (i < N) {
+      const long long tv = t[i];
+      if (tv != 0 && tv != pad_id) { k = __float_as_uint(rp[i]); c += 1; }
+    }
+    keys[j] = k;
+  }
+
   // 1. number of maskable positions
   if (tid == 0) sh_count = 0;
   __syncthreads();
-  int c = 0;
-  for (int i = tid; i < N; i += 1024) c += (t[i] != 0 && t[i] != pad_id) ? 1 : 0;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
   if ((tid & 63) == 0) atomicAdd(&sh_count, c);
@@ -56,11 +71,10 @@ __global__ __launch_bounds__(1024) void s1_mask_kernel(const int64_t* __restrict
       const unsigned himask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
       for (int i = tid; i < 256; i += 1024) hist[i] = 0;
       __syncthreads();
-      for (int i = tid; i < N; i += 1024) {
-        if (t[i] != 0 && t[i] != pad_id) {
-          const unsigned key = __float_as_uint(rp[i]);
-          if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255], 1);
-        }
+#pragma unroll
+      for (int j = 0; j < S1_PER_THREAD; ++j) {
+        const unsigned key = keys[j];
+        if (key != 0xFFFFFFFFu && (key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255], 1);
       }
       __syncthreads();
       if (tid < 256) {  // the digit d with  #(keys of a larger digit) < need <= #(keys of digit >= d)
@@ -80,41 +94,38 @@ __global__ __launch_bounds__(1024) void s1_mask_kernel(const int64_t* __restrict
   }
   // now: keys > prefix are all picked; `need` of the keys == prefix are picked, lowest positions first
 
-  // 3. write-out in position order, ranking the ties with a workgroup prefix count
-  if (tid == 0) sh_tiebase = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < N; i0 += 1024) {
-    const int i = i0 + tid;
-    long long tv = 0;
-    bool maskable = false, above = false, tie = false;
-    if (i < N) {
-      tv = t[i];
-      maskable = (tv != 0 && tv != pad_id) && k > 0;
-      const unsigned key = __float_as_uint(rp[i]);
-      above = maskable && key > prefix;
-      tie = maskable && key == prefix;
-    }
-    // rank of this tie among the ties of the chunk (position order)
+  // 3. write-out.  Ties are ranked in position order (position = tid + 1024 j): the number of ties per (chunk j,
+  // wave) goes to LDS, one thread turns the table into exclusive prefix sums in (j, wave) order, and every thread
+  // adds the ties of lower lanes of its own wave (ballot).
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < S1_PER_THREAD; ++j) {
+    const bool tie = keys[j] != 0xFFFFFFFFu && k > 0 && keys[j] == prefix;
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(tie);
-    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) tie_cnt[j * 16 + wv] = __builtin_popcountll(bal);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int e = 0; e < S1_PER_THREAD * 16; ++e) { const int v = tie_cnt[e]; tie_cnt[e] = run; run += v; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < S1_PER_THREAD; ++j) {
+    const int i = tid + 1024 * j;
+    const unsigned key = keys[j];
+    const bool maskable = key != 0xFFFFFFFFu && k > 0;
+    const bool above = maskable && key > prefix;
+    const bool tie = maskable && key == prefix;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(tie);
     const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wv] = __builtin_popcountll(bal);
-    __syncthreads();
-    int wbase = sh_tiebase;
-    for (int j = 0; j < wv; ++j) wbase += wave_cnt[j];
-    const bool picked = above || (tie && (wbase + before) < need);
+    const bool picked = above || (tie && (tie_cnt[j * 16 + wv] + before) < need);
     if (i < N) {
+      const long long tv = t[i];
       const bool rep = rr[i] < replace_prob;
       masked[base + i] = (picked && rep) ? mask_id : tv;
       labels[base + i] = picked ? tv : pad_id;
     }
-    __syncthreads();
-    if (tid == 0) {
-      int tot = 0;
-      for (int j = 0; j < 16; ++j) tot += wave_cnt[j];
-      sh_tiebase += tot;
-    }
-    __syncthreads();
   }
 }
 

@@ -116,3 +116,12 @@ def test_accuracy_matches_the_loop_definition(b, n, c):
     want_c = (keep * (final == labels)).sum(-1)
     assert torch.equal(counts.cpu()[:, 0].long(), want_c) and torch.equal(counts.cpu()[:, 1].long(), want_n)
     torch.testing.assert_close(ratio.cpu(), torch.true_divide(want_c, want_n), equal_nan=True, rtol=1e-6, atol=0)
+
+
+def test_mask_rejects_cells_longer_than_the_register_budget(s1):
+    from scmomer_amd._lib import ScmError
+    tok = torch.ones((1, 20481), dtype=torch.int64, device=DEV)
+    with pytest.raises(ScmError):
+        s1.data_mask_device(tok, 0.15, 0.9, 6, 6)
+    mi, lab = s1.data_mask_device(tok[:, :20480], 0.15, 0.9, 6, 6)   # the largest supported length
+    assert int((lab != 6).sum()) == int(np.ceil(np.float32(20480) * np.float32(0.15)))
