@@ -93,3 +93,25 @@ if filt == "wsweep":
             wg, rd = tr["wgrad"][0] / 10, tr["wgrad_reduce"][0] / 10
             print(f"P {P:5d} slices {slices:4d} WGs {ptiles * slices:4d}  wgrad {wg * 1e3:7.1f} us ({by / wg / 1e9:5.2f} TB/s)  "
                   f"reduce {rd * 1e3:6.1f} us  slab {ws.numel() * 4 / 1e6:6.1f} MB")
+
+# ---- do two independent weight-gradient products overlap when issued on two streams? (filter "wpair")
+if filt == "wpair":
+    pm1 = rnd(T, 800); qm1 = rnd(T, 200); g1 = torch.zeros(800, 200, device=dev); b1 = torch.zeros(800, device=dev)
+    pm2 = rnd(T, 800); qm2 = rnd(T, 200); g2 = torch.zeros(200, 800, device=dev)
+    pm3 = rnd(T, 1920); g3 = torch.zeros(1920, 200, device=dev)
+    pm4 = rnd(T, 640); g4 = torch.zeros(200, 640, device=dev)
+    s1_, s2_ = torch.cuda.Stream(), torch.cuda.Stream()
+    def seq(a, b):
+        a(); b()
+    def par(a, b):
+        cur = torch.cuda.current_stream()
+        s1_.wait_stream(cur); s2_.wait_stream(cur)
+        with torch.cuda.stream(s1_): a()
+        with torch.cuda.stream(s2_): b()
+        cur.wait_stream(s1_); cur.wait_stream(s2_)
+    A = lambda: ops.wgrad(pm1, qm1, g1, b1, False, False)
+    B = lambda: ops.wgrad(pm2, qm2, g2, None, True, False)
+    Cq = lambda: ops.wgrad(pm3, qm1, g3, None, False, False)
+    Do = lambda: ops.wgrad(pm4, qm2, g4, None, True, False)
+    for name, a, b in (("ffn pair (w1+bias, w2)", A, B), ("attn pair (qkv, wo)", Cq, Do)):
+        print(f"{name:28s} sequential {timeit(lambda: seq(a, b)) * 1e6:7.1f} us   two streams {timeit(lambda: par(a, b)) * 1e6:7.1f} us")
