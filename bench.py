@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""S1 RNA masked-autoencoding pretrain micro-step benchmark (BASELINE.json config 2/3).
+"""S1 RNA masked-autoencoding pretrain micro-step benchmark (3 cells x 16,906 genes per GPU per micro-step).
 
 One step = mask 15 % of the expressed genes of a 3-cell batch (s1_pretrain_rna.py:290), run the
 Performer RNA encoder forward (16,906 gene tokens, depth 6, dim 200, 10 heads, 266 features),
@@ -53,7 +53,7 @@ def build_model(device):
     gen = torch.Generator().manual_seed(0)
     with torch.no_grad():              # synthetic gene2vec table (float64, last row zero as in the reference)
         model.pos_emb.emb.weight[:N_GENES] = torch.randn((N_GENES, 200), generator=gen, dtype=torch.float64)
-    model.fix_projection_matrices_()   # feature redraw disabled, as BASELINE.json prescribes
+    model.fix_projection_matrices_()   # feature redraw disabled for the measurement (fixed projections)
     return model.to(device)
 
 

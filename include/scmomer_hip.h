@@ -2,7 +2,7 @@
  *
  * The reference (nobody927/scMomer) is pure Python/PyTorch and has no FFI of its own; each entry
  * point below replaces the aten-op group of the cited reference lines.  A binding only needs
- * device pointers, sizes and a stream (ctypes stub: INTEGRATION.md).
+ * device pointers, sizes and a stream (bound with ctypes in scmomer_amd/_lib.py).
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless marked "host"; buffers are caller-owned, nothing

@@ -171,7 +171,7 @@ def test_batch_composition_couples_keys():
 
 
 def test_full_size_forward_vs_oracle():
-    """BASELINE config shape: 16,906 gene tokens, depth 6, batch 1, against the float32 CPU oracle."""
+    """The reference's CPU-runnable case: 16,906 gene tokens, depth 6, batch 1, against the float32 CPU oracle."""
     n, depth = 16906, 6
     p = O.make_params(2024, depth=depth, max_seq_len=n)
     cells = O.synthetic_cells(2024, 1, n)
