@@ -277,7 +277,9 @@ class S1Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread-local capture mode: device calls made meanwhile by other threads of the process (the collective
+        # library's watchdog polls events) must not invalidate the recording
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             body()
         for a, s_ in zip(self.accs, saved):                  # warm-up and recording passes do not count
             a.copy_(s_)
