@@ -39,6 +39,18 @@ const char* scm_last_error(void); /* host */
 /* ---- parameter preparation ------------------------------------------------------------- */
 /* f32 weight [rows,cols] -> bf16 copy and/or bf16 transposed copy [cols,rows] (either may be NULL). */
 int scm_cast_weight(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
+/* The same for a table of n weights in ONE launch (after an optimizer step).  The table lives in DEVICE memory;
+ * entry i casts src [R,C] f32 into dst[r * ldd + c] and dstT[c * ldt + r] (bf16; either may be NULL), so that
+ * several sources can fill slices of one fused matrix (q/k/v weights -> the fused [3*inner, dim] operand). */
+typedef struct {
+  const float* src;
+  int32_t R, C;
+  void* dst;
+  int64_t ldd;
+  void* dstT;
+  int64_t ldt;
+} scm_cast_item;
+int scm_cast_weights_batch(const scm_cast_item* items /* device */, int n, void* stream);
 /* FastAttention.projection_matrix f32 [266,64] (performer_pytorch.py:209) -> zero-padded bf16 [288,64]. */
 int scm_prep_omega(const float* omega, void* omega_b, void* stream);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "scm_version": (i32, []),
     "scm_last_error": (C.c_char_p, []),
     "scm_cast_weight": (i32, [vp, i32, i32, vp, vp, vp]),
+    "scm_cast_weights_batch": (i32, [vp, i32, vp]),
     "scm_prep_omega": (i32, [vp, vp, vp]),
     "scm_embed_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "scm_embed_bwd_ws_floats": (i64, [i64, i32, i32]),

@@ -93,6 +93,12 @@ int scm_trace_collect(double* ms, double* flops, double* bytes, int64_t* launche
 }
 const char* scm_last_error(void) { return g_err; }
 
+int scm_cast_weights_batch(const scm_cast_item* items, int n, void* stream) {
+  SCM_REQ(items && n > 0 && n <= 65535, "scm_cast_weights_batch: bad arguments");
+  SCM_HIP(cast_weights_batch(items, n, (hipStream_t)stream), "scm_cast_weights_batch");
+  return 0;
+}
+
 int scm_cast_weight(const float* src, int rows, int cols, void* dst, void* dstT, void* stream) {
   SCM_REQ(src && rows > 0 && cols > 0 && (dst || dstT), "scm_cast_weight: bad arguments");
   SCM_HIP(cast_weight(src, rows, cols, dst, dstT, (hipStream_t)stream), "scm_cast_weight");

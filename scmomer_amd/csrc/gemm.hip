@@ -805,6 +805,19 @@ __global__ void cast_weight_kernel(const float* __restrict__ src, int R, int C, 
   if (dstT) dstT[(long)c * R + r] = v;
 }
 
+// The same for a whole table of weights in one launch (grid.y = entry): an entry casts src [R,C] into
+// dst[r * ldd + c] and dstT[c * ldt + r], so several sources can fill slices of one fused matrix.
+__global__ void cast_weights_batch_kernel(const CastItem* __restrict__ items) {
+  const CastItem it = items[blockIdx.y];
+  const long n = (long)it.R * it.C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / it.C), c = (int)(idx % it.C);
+    const bf16 v = (bf16)it.src[idx];
+    if (it.dst) ((bf16*)it.dst)[(long)r * it.ldd + c] = v;
+    if (it.dstT) ((bf16*)it.dstT)[(long)c * it.ldt + r] = v;
+  }
+}
+
 }  // namespace scm
 
 // ------------------------------------------------------------------------------------------
@@ -949,6 +962,12 @@ hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, flo
   Traced tr(K_WGRAD_REDUCE, 0, s);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slab, S, P, Q, grad, bias, trans,
                      accumulate);
+  return hipGetLastError();
+}
+
+hipError_t cast_weights_batch(const CastItem* items, int n, hipStream_t s) {
+  Traced tr(K_CAST, 0, s);
+  hipLaunchKernelGGL(cast_weights_batch_kernel, dim3(64, n), dim3(256), 0, s, items);
   return hipGetLastError();
 }
 

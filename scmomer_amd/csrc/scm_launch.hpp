@@ -1,6 +1,7 @@
 // Host-side launch interface shared by the kernel translation units and the C ABI wrappers.
 #pragma once
 #include "scm_common.hpp"
+#include "../../include/scmomer_hip.h"
 
 namespace scm {
 
@@ -82,6 +83,8 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
 hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, float* bias, int trans, int accumulate,
                         hipStream_t s);
 hipError_t cast_weight(const float* src, int R, int C, void* dst, void* dstT, hipStream_t s);
+using CastItem = ::scm_cast_item;   // the C ABI's table entry
+hipError_t cast_weights_batch(const CastItem* items, int n, hipStream_t s);
 
 // norm_embed.hip
 hipError_t embed_fwd(const int64_t* tok, const float* E, const double* G, int B, int N, int D, int V, float* out,

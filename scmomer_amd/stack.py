@@ -105,14 +105,76 @@ class WeightCache:
         return out
 
 
+def _attn_ver(p) -> tuple:
+    return (p["wq"].device,) + _ver(p["wq"], p["wk"], p["wv"], p["wo"], p["omega"], p["bq"], p["bk"], p["bv"])
+
+
+def _ffn_ver(p) -> tuple:
+    return (p["w1"].device,) + _ver(p["w1"], p["w2"])
+
+
+def _cast_table(cache: WeightCache, layers) -> Optional[Tuple[torch.Tensor, int, tuple]]:
+    """Device table of scm_cast_item entries covering every weight matrix of the stack (q/k/v weights fill slices
+    of the fused operand), or None when some weight is not a contiguous f32 tensor with an existing copy."""
+    import struct
+    rows = []
+    ptrs = []
+    for li, (ap, fp) in enumerate(layers):
+        ha, hf = cache.store.get(("a", li)), cache.store.get(("f", li))
+        if ha is None or hf is None or ap["bq"] is not None:
+            return None
+        wa, wf = ha[1], hf[1]
+        inner, d = ap["wq"].shape
+        srcs = [(ap["wq"], wa["wqkv"], 0, d, wa["wqkv_t"], 0, 3 * inner),
+                (ap["wk"], wa["wqkv"], inner * d, d, wa["wqkv_t"], inner, 3 * inner),
+                (ap["wv"], wa["wqkv"], 2 * inner * d, d, wa["wqkv_t"], 2 * inner, 3 * inner),
+                (ap["wo"], wa["wo"], 0, inner, wa["wo_t"], 0, d),
+                (fp["w1"], wf["w1"], 0, d, wf["w1_t"], 0, fp["w1"].shape[0]),
+                (fp["w2"], wf["w2"], 0, fp["w2"].shape[1], wf["w2_t"], 0, d)]
+        for src, dst, dst_off, ldd, dstt, dstt_off, ldt in srcs:
+            if src.dtype != F32 or not src.is_contiguous() or not dst.is_contiguous() or not dstt.is_contiguous():
+                return None
+            r, c = src.shape
+            rows.append(struct.pack("<QiiQqQq", src.data_ptr(), r, c, dst.data_ptr() + 2 * dst_off, ldd,
+                                    dstt.data_ptr() + 2 * dstt_off, ldt))
+            ptrs.append(src.data_ptr())
+    if not rows:
+        return None
+    table = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(layers[0][0]["wq"].device)
+    return table, len(rows), tuple(ptrs)
+
+
 def refresh_weights(owner) -> None:
     """Bring the bf16 weight copies of a PerformerLM / Performer up to date now (in place).  Needed only by callers
-    that replay a captured graph of the step: call it after every weight update, outside the graph."""
+    that replay a captured graph of the step: call it after every weight update, outside the graph.  Once the
+    copies exist, ONE kernel launch recasts every weight matrix of the stack (a device table lists them)."""
     performer = getattr(owner, "performer", owner)
     cache = _cache_of(owner)
-    for li, (f, g) in enumerate(performer.net.layers):
-        cache.attn(li, attn_params(f))
-        cache.ffn(li, ffn_params(g))
+    layers = [(attn_params(f), ffn_params(g)) for f, g in performer.net.layers]
+    tab = owner.__dict__.get("_scm_cast_table")
+    if tab is not None and tab[2] != tuple(p.data_ptr() for ap, fp in layers
+                                          for p in (ap["wq"], ap["wk"], ap["wv"], ap["wo"], fp["w1"], fp["w2"])):
+        tab = None                               # parameters were re-allocated (moved, re-created): rebuild
+    if tab is None:
+        for li, (ap, fp) in enumerate(layers):   # creates or refreshes the copies layer by layer
+            cache.attn(li, ap)
+            cache.ffn(li, fp)
+        owner.__dict__["_scm_cast_table"] = _cast_table(cache, layers)
+        return
+    stale = False
+    for li, (ap, fp) in enumerate(layers):
+        ha, hf = cache.store[("a", li)], cache.store[("f", li)]
+        va, vf = _attn_ver(ap), _ffn_ver(fp)
+        if ha[0] != va or hf[0] != vf:
+            stale = True
+            if ha[0][5] != va[5]:                # the projection matrix changed (redraw): its own small kernel
+                ops.prep_omega(ap["omega"].detach().to(F32).contiguous(), out=ha[1]["omega_b"])
+            cache.store[("a", li)] = (va, ha[1])
+            cache.store[("f", li)] = (vf, hf[1])
+    if stale:
+        from ._lib import check, lib
+        check(lib.scm_cast_weights_batch(tab[0].data_ptr(), tab[1], torch.cuda.current_stream().cuda_stream),
+              "scm_cast_weights_batch")
 
 
 def _cache_of(owner) -> WeightCache:

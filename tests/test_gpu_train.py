@@ -97,3 +97,36 @@ def test_fit_from_device_csr_checkpoint_and_resume(mods, tmp_path):
     with torch.no_grad():
         assert torch.equal(m(tok), m2(tok))
     assert tr2.optimizer.state_dict()["state"].keys() == ck["optimizer_state_dict"]["state"].keys()
+
+
+def test_batched_weight_refresh_matches_per_matrix_casts(mods):
+    """after a weight update, ONE launch recasts every matrix of the stack: the copies equal the bf16 rounding of
+    the weights (q/k/v fused, plain and transposed), also after a projection redraw"""
+    from scmomer_amd import stack
+    m = _model(130)
+    tok = torch.randint(0, 6, (2, 130), device=DEV)
+    with torch.no_grad():
+        m(tok)                                               # creates the copies
+        for rep in range(3):                                 # 1st: builds the table, then the batched path
+            for p in m.parameters():
+                if p.dtype == torch.float32:
+                    p.add_(0.01 * (rep + 1))
+            if rep == 2:
+                fa = m.performer.net.layers[0][0].fn.fast_attention
+                fa.redraw_projection_matrix(DEV)
+            stack.refresh_weights(m)
+            cache = stack._cache_of(m)
+            for li, (f, g) in enumerate(m.performer.net.layers):
+                wa, wf = cache.store[("a", li)][1], cache.store[("f", li)][1]
+                sa, ff = f.fn, g.fn.fn
+                fused = torch.cat([sa.to_q.weight, sa.to_k.weight, sa.to_v.weight], 0).to(torch.bfloat16)
+                assert torch.equal(wa["wqkv"], fused) and torch.equal(wa["wqkv_t"], fused.t().contiguous())
+                assert torch.equal(wa["wo"], sa.to_out.weight.to(torch.bfloat16))
+                assert torch.equal(wa["wo_t"], sa.to_out.weight.to(torch.bfloat16).t().contiguous())
+                assert torch.equal(wf["w1"], ff.w1.weight.to(torch.bfloat16))
+                assert torch.equal(wf["w1_t"], ff.w1.weight.to(torch.bfloat16).t().contiguous())
+                assert torch.equal(wf["w2_t"], ff.w2.weight.to(torch.bfloat16).t().contiguous())
+        assert m.__dict__.get("_scm_cast_table") is not None
+        want = m.performer.net.layers[0][0].fn.fast_attention.projection_matrix
+        got = stack._cache_of(m).store[("a", 0)][1]["omega_b"][:266].float()
+        assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max())
