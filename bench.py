@@ -39,9 +39,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-all", action="store_true", help="time every kernel (per-kernel table to stderr)")
     ap.add_argument("--eager", action="store_true", help="drive every launch from Python instead of a HIP graph")
-    ap.add_argument("--mode", choices=("train", "extract"), default="train",
+    ap.add_argument("--mode", choices=("train", "extract", "finetune"), default="train",
                     help="train: the S1 micro-step (the headline metric); extract: forward-only cell-embedding "
-                         "extraction (scMomer.get_cell_embedding), a secondary figure")
+                         "extraction (scMomer.get_cell_embedding); finetune: the cell-type fine-tune step "
+                         "(frozen encoder except its second-to-last layer, norm and head); secondary figures")
     return ap.parse_args()
 
 
@@ -181,6 +182,73 @@ def run_extract(args, world, rank, device):
             "cpu_baseline": None, "kernels": kernels}))
 
 
+def run_finetune(args, world, rank, device):
+    """Cell-type fine-tune step of train_celltype.py:126-175: scMomer.forward(mode='one') with a classifier head,
+    cross entropy, backward (only the encoder's final norm, its second-to-last layer, the per-gene head,
+    rna_projection and the classifier are trainable: the backward stops below that layer), clip 5, Adam.  One step
+    = one batch of 6 cells (the script's default)."""
+    import types
+    import torch.distributed as dist
+    import scmomer_amd as S
+    from scmomer_amd import dist as sdist
+    from scmomer_amd import stack
+    batch = args.batch if args.batch != BATCH else 6
+    torch.manual_seed(2024)
+    cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+    model = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(N_GENES, 128))
+    model.sub_task = torch.nn.Sequential(torch.nn.Linear(128, 64), torch.nn.Dropout(0.2), torch.nn.ReLU(),
+                                         torch.nn.Linear(64, 20))
+    for p in model.parameters():
+        p.requires_grad = False
+    lm = model.rna_model.model
+    for group in (lm.norm, lm.performer.net.layers[-2], lm.to_out, model.rna_projection, model.sub_task):
+        for p in group.parameters():
+            p.requires_grad = True
+    lm.fix_projection_matrices_()
+    model = model.to(device).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    averager = sdist.GradientAverager(params)
+    gen = torch.Generator().manual_seed(100 + rank)
+    cells = [((torch.rand((batch, N_GENES), generator=gen) < 0.15) *
+              torch.distributions.Gamma(2.0, 1 / 1.2).sample((batch, N_GENES))).float().to(device) for _ in range(2)]
+    labels = torch.randint(0, 20, (batch,), generator=gen).to(device)
+
+    def step(i):
+        logits = model(None, cells[i % 2], mode='one', reconstruct=False)
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        opt.zero_grad()
+        loss.backward()
+        averager.average_()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        return loss
+
+    for i in range(max(args.warmup, 1)):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = sdist.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "cells/sec, cell-type fine-tune step (frozen encoder below its second-to-last layer, 16.9k genes)",
+            "value": world * batch * args.steps / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "scMomer.forward(mode='one') + classifier + CE + partial backward + clip + Adam",
+                       "cells_per_gpu_per_step": batch, "gene_tokens": N_GENES, "depth": 6, "dim": 200, "heads": 10,
+                       "nb_features": 266, "parallelism": f"dp{world}", "launch": "eager"},
+            "final_loss": float(loss.item()), "roofline": None, "cpu_baseline": None}))
+
+
 def _say(msg):
     if os.environ.get("SCM_BENCH_VERBOSE") == "1":
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -205,8 +273,8 @@ def main():
                                 world_size=world, rank=rank)
 
     _say("process group up")
-    if args.mode == "extract":
-        run_extract(args, world, rank, device)
+    if args.mode in ("extract", "finetune"):
+        (run_extract if args.mode == "extract" else run_finetune)(args, world, rank, device)
         if world > 1:
             dist.destroy_process_group()
         return
