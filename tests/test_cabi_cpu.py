@@ -80,3 +80,21 @@ def test_product_code_never_touches_the_oracle():
                 text = open(os.path.join(base, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "oracle/" not in text and "performer_oracle" not in text, f
+
+
+def test_plan_fills_whole_rounds_of_workgroups():
+    """chunks per (cell, head) are chosen so that the attention launches are a nearly whole number of rounds of 256
+    workgroups; the key-stabiliser partial count follows the context chunks (9 waves each)"""
+    from scmomer_amd._lib import FavorPlan, lib
+    for b, h, n in [(1, 10, 16906), (3, 10, 16906), (16, 10, 16906), (24, 10, 16906), (64, 10, 16906), (2, 3, 131),
+                    (1, 1, 40)]:
+        plan = FavorPlan()
+        assert lib.scm_favor_make_plan(b, h, n, C.byref(plan)) == 0
+        assert plan.kmax_chunks == 9 * plan.ctx_chunks
+        assert 1 <= plan.apply_chunks <= (n + 31) // 32 and 1 <= plan.ctx_chunks <= (n + 63) // 64
+        if n == 16906:
+            rounds = b * h * plan.apply_chunks / 256
+            assert rounds / -(-rounds // 1) >= 0.9, (b, plan.apply_chunks)
+    plan = FavorPlan()
+    lib.scm_favor_make_plan(3, 10, 16906, C.byref(plan))
+    assert (plan.apply_chunks, plan.ctx_chunks) == (8, 8)          # the benchmark configuration: one round
