@@ -51,14 +51,29 @@ SCM_DEV float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 SCM_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
 SCM_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
 
+// Lane exchange inside a row of 16 lanes through the data-parallel-primitive path of the vector ALU (no LDS-pipe
+// round trip): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
+template <int CTRL>
+SCM_DEV float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// Sum over the 64 lanes, result in every lane: four exchanges inside each row of 16 lanes, then two across rows.
 SCM_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
   return v;
 }
 SCM_DEV float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
   return v;
 }
 
