@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   f32x4 acc[MAXV];
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (long t = wave; t < T; t += nwaves) {
+#pragma unroll 4
+  for (long t = wave; t < T; t += nwaves) {   // no stores in the loop: unrolling keeps four rows' loads in flight
     const int id = (int)tok[t];
     f32x4 x = active ? *(const f32x4*)(dx + t * D + 4 * l) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
