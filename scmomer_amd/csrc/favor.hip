@@ -254,7 +254,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float v = (float)xs_r[j]; ss += v * v; }
-    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+    ss += dpp_move<0xB1>(ss); ss += dpp_move<0x4E>(ss); ss += dpp_move<0x141>(ss);   // the 8 lanes of a row
     bf16x8 yv = ys_r;
     if (MODE == 1) {
       const float inv = 1.f / den_r;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
     const bf16x8 ov = *(const bf16x8*)(omega_b + (long)(32 * tile + (tid >> 3)) * DH + 8 * (tid & 7));
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float v = (float)ov[j]; ss += v * v; }
-    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+    ss += dpp_move<0xB1>(ss); ss += dpp_move<0x4E>(ss); ss += dpp_move<0x141>(ss);   // the 8 lanes of a row
   }
   float gmax = 0.f;
   if (stab) {   // max over all partial stabilisers, by the whole workgroup
