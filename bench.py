@@ -254,9 +254,51 @@ def _say(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` started directly (no torchrun): this process stays off the GPU, starts N copies of
+    itself as ranks 0..N-1 (one per GPU, env:// rendezvous on 127.0.0.1, the layout torchrun would give them),
+    waits for all of them and relays rank 0's JSON line.  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if os.environ.get("SCM_BENCH_ONE_DEVICE") != "1" and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), RANK=str(r),
+                   LOCAL_RANK=str(r))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    if any(codes):
+        sys.stdout.write(out0 or "")
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return next(c for c in codes if c) or 1
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None or json.loads(line).get("n_gpus") != n:
+        sys.stdout.write(out0 or "")
+        print(f"bench.py: rank 0 did not report n_gpus == {n}", file=sys.stderr)
+        return 3
+    print(line)
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

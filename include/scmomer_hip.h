@@ -128,6 +128,22 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
                   const float* den, const float* kmax, const int64_t* kmax_idx, scm_view4 dq, scm_view4 dk,
                   scm_view4 dv, void* dctx_bf16, float* dz, float* dsums, float* dden, float* ws, void* stream);
 
+/* ---- the reference's free functions with MATERIALISED feature maps, exact f32 arithmetic (the model path above never
+ *      writes q'/k' to memory; these serve callers of the functions themselves) -------------------------------
+ * softmax_kernel(data, projection_matrix, is_query, normalize_data, eps), performer_pytorch.py:67-92:
+ *   data f32 [B*H, N, 64] contiguous, projection f32 [M, 64], M <= 320 -> out f32 [B*H, N, M] =
+ *   M^-1/2 * (exp((c data) proj^T - c^2 |data|^2 / 2 - stab) + eps), c = 64^-1/4 (1 when !normalize_data);
+ *   stab = per-token max of the scores (is_query) or ONE max over the whole tensor (keys: two passes, ws of
+ *   scm_feature_map_ws_floats(B*H, N) floats; ws may be NULL for queries). */
+int64_t scm_feature_map_ws_floats(int64_t BH, int N);
+int scm_feature_map(const float* data, const float* projection, int64_t BH, int N, int M, int is_query,
+                    int normalize_data, float eps, float* out, float* ws, void* stream);
+/* linear_attention(q, k, v), performer_pytorch.py:144-149: q', k' f32 [B*H, N, M], v f32 [B*H, N, 64] ->
+ * out f32 [B*H, N, 64] = (q' (k'^T v)) / (q' . sum_n k').  ws: scm_linear_attention_ws_floats(B*H, N, M) floats. */
+int64_t scm_linear_attention_ws_floats(int64_t BH, int N, int M);
+int scm_linear_attention(const float* qf, const float* kf, const float* v, int64_t BH, int N, int M, float* out,
+                         float* ws, void* stream);
+
 /* ---- final LayerNorm + head: performer_pytorch.py:628-634 (Linear(dim,num_tokens)); rna_encoder.py:5-16
  *      (1x200 conv == dot product, + ReLU; C = 1, relu = 1) -------------------------------------- */
 /* enc (may be NULL) f32 [T,D] = LN(x); out (may be NULL when C == 0) f32 [T,C]. */

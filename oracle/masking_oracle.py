@@ -74,3 +74,30 @@ def data_mask(data: np.ndarray, mask_prob: float, replace_prob: float, pad_token
     masked_input = np.where(mask & replace, np.int64(mask_token_id), data)
     labels = np.where(mask, data, np.int64(pad_token_id))
     return masked_input, labels
+
+
+# ---------------------------------------------------------------------------
+# torch-tensor front ends (what CPU tests of the training driver inject as mask_fn)
+# ---------------------------------------------------------------------------
+def bin_s1_tensor(rows, class_limit: int = 7):
+    import torch
+    return torch.from_numpy(bin_s1(rows.detach().cpu().numpy(), class_limit)).to(rows.device)
+
+
+def bin_scmomer_tensor(x):
+    import torch
+    return torch.from_numpy(bin_scmomer(x.detach().cpu().numpy())).to(x.device)
+
+
+def data_mask_tensor(data, mask_prob: float, replace_prob: float, pad_token_id: int, mask_token_id: int,
+                     rand_pick=None, rand_replace=None):
+    """data_mask on torch tensors.  Missing draws are made with torch on data's device in the reference's order
+    (s1_pretrain_rna.py:105 then :89,118), so a seeded torch generator reproduces the reference's masks."""
+    import torch
+    if rand_pick is None:
+        rand_pick = torch.rand(data.shape, device=data.device)
+    if rand_replace is None:
+        rand_replace = torch.zeros_like(data).float().uniform_(0, 1)
+    mi, lab = data_mask(data.detach().cpu().numpy(), mask_prob, replace_prob, pad_token_id, mask_token_id,
+                        rand_pick.detach().cpu().numpy(), rand_replace.detach().cpu().numpy())
+    return torch.from_numpy(mi).to(data.device), torch.from_numpy(lab).to(data.device)

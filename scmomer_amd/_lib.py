@@ -46,6 +46,10 @@ SIGNATURES = {
     "scm_favor_fwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, vp, View4, View4, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scm_favor_bwd": (i32, [C.POINTER(FavorPlan), View4, View4, View4, View4, View4, vp, vp, vp, vp, vp, vp, vp, vp,
                             View4, View4, View4, vp, vp, vp, vp, vp, vp]),
+    "scm_feature_map_ws_floats": (i64, [i64, i32]),
+    "scm_feature_map": (i32, [vp, vp, i64, i32, i32, i32, i32, C.c_float, vp, vp, vp]),
+    "scm_linear_attention_ws_floats": (i64, [i64, i32, i32]),
+    "scm_linear_attention": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
     "scm_trace_kernel_count": (i32, []),
     "scm_trace_kernel_name": (C.c_char_p, [i32]),
     "scm_trace_enable": (i32, [i32]),

@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <vector>
+#include <math.h>
 
 using namespace scm;
 
@@ -48,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -298,6 +299,37 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   // 4. gradient through the global key stabiliser lands on one token
   SCM_HIP(favor_kfix(kmax, (const long long*)kmax_idx, plan->kmax_chunks * B * H, ws, plan->apply_chunks * B * H, omega_b, oview(dk), H,
                      N, s), "favor_kfix");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- free functions (materialised, f32)
+int64_t scm_feature_map_ws_floats(int64_t BH, int N) { return (BH > 0 && N > 0) ? feature_map_ws_floats(BH, N) : 0; }
+
+int scm_feature_map(const float* data, const float* projection, int64_t BH, int N, int M, int is_query,
+                    int normalize_data, float eps, float* out, float* ws, void* stream) {
+  SCM_REQ(data && projection && out, "scm_feature_map: null pointer");
+  SCM_REQ(is_query || ws, "scm_feature_map: key features need the workspace (scm_feature_map_ws_floats)");
+  SCM_REQ(BH > 0 && BH <= 65535 && N > 0 && M > 0 && M <= FREE_MAX_FEATURES && BH * N < (1ll << 31),
+          "scm_feature_map: need 0 < B*H <= 65535, 0 < M <= %d (got B*H=%lld N=%d M=%d)", FREE_MAX_FEATURES,
+          (long long)BH, N, M);
+  SCM_REQ(aligned16(data) && aligned16(projection), "scm_feature_map: data/projection must be 16-byte aligned");
+  // the scalars as the reference forms them: Python doubles rounded to f32 where they meet the f32 tensor
+  const double nrm = normalize_data ? pow((double)DH, -0.25) : 1.0;
+  SCM_HIP(feature_map(data, projection, BH, N, M, is_query, (float)nrm, (float)(nrm * nrm),
+                      (float)pow((double)M, -0.5), eps, out, ws, (hipStream_t)stream), "scm_feature_map");
+  return 0;
+}
+
+int64_t scm_linear_attention_ws_floats(int64_t BH, int N, int M) {
+  return (BH > 0 && N > 0 && M > 0) ? linear_attention_ws_floats(BH, N, M) : 0;
+}
+
+int scm_linear_attention(const float* qf, const float* kf, const float* v, int64_t BH, int N, int M, float* out,
+                         float* ws, void* stream) {
+  SCM_REQ(qf && kf && v && out && ws, "scm_linear_attention: null pointer");
+  SCM_REQ(BH > 0 && BH <= 65535 && N > 0 && M > 0 && M <= FREE_MAX_FEATURES && BH * N < (1ll << 31),
+          "scm_linear_attention: need 0 < B*H <= 65535, 0 < M <= %d", FREE_MAX_FEATURES);
+  SCM_HIP(linear_attention(qf, kf, v, BH, N, M, out, ws, (hipStream_t)stream), "scm_linear_attention");
   return 0;
 }
 

@@ -934,13 +934,10 @@ size_t favor_apply_lds() { return APPLY_LDS; }
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s) {
   a.chunk_len = round_up((a.N + nchunks - 1) / nchunks, 32);
   const size_t lds = favor_apply_lds();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)favor_apply_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)favor_apply_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)favor_apply_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> ready[3];
+  const void* kfn = mode == 0 ? (const void*)favor_apply_kernel<0>
+                              : (mode == 1 ? (const void*)favor_apply_kernel<1> : (const void*)favor_apply_kernel<2>);
+  if (hipError_t e = ensure_dynamic_lds(kfn, lds, ready[mode]); e != hipSuccess) return e;
   dim3 grid(nchunks, B * a.H);
   // algorithmic FLOPs per (token, head): mode 0: scores + q'C + q'.z = 68,628; mode 1: dnum C^T + dden z +
   // dS Omega = 68,628; mode 2: v dC^T + k' dC + dS Omega = 102,144 (recomputed scores not counted)

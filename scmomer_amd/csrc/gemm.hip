@@ -859,11 +859,9 @@ static hipError_t launch_skinny(const void* A, long lda, const bf16* W, long ldw
   if (grid > total) grid = total;
   Traced tr(K_GEMM_SKINNY + EPI, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
   const size_t lds = 2 * SK_WBYTES + (size_t)((N + 63) / 64) * 64 * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<A_F32, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr = true;
-  }
+  static std::atomic<unsigned long long> ready;
+  if (hipError_t e = ensure_dynamic_lds((const void*)gemm_skinny_kernel<A_F32, EPI>, 96 * 1024, ready); e != hipSuccess)
+    return e;
   hipLaunchKernelGGL((gemm_skinny_kernel<A_F32, EPI>), dim3((unsigned)grid), dim3(256), lds, s, A, lda, W, ldw,
                      M, N, K, e);
   return hipGetLastError();
@@ -883,11 +881,8 @@ static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, 
   if (!A_F32 && N <= 224 && K >= 128 && (long)M * lda * 2 < lim && (long)N * ldw * 2 < lim &&
       (EPI != EPI_F32_BIAS_RES || !e.resid || (long)M * e.ldr * 4 < lim)) {
     const size_t lds = (size_t)2 * GD_STAGE;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
-    }
+    static std::atomic<unsigned long long> ready;
+    if (hipError_t e = ensure_dynamic_lds((const void*)gemm_nt_dma_kernel<EPI>, lds, ready); e != hipSuccess) return e;
     // whole rounds of 256 workgroups with at most 224 rows each; small problems: one workgroup per 32 rows
     long grid = 256 * (((long)M + 256l * GD_ROWS - 1) / (256l * GD_ROWS));
     if (grid > (M + 31) / 32) grid = (M + 31) / 32;
@@ -930,12 +925,9 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
   if (!q_f32 && (long)T * ldp * 2 < lim && (long)T * ldq * 2 < lim) {
     // bf16 operands: asynchronous global->LDS pipeline
     const size_t lds = (size_t)WD_NSTAGE * WD_STAGE;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
-    }
+    static std::atomic<unsigned long long> ready[2];
+    const void* kfn = ones ? (const void*)wgrad_dma_kernel<true> : (const void*)wgrad_dma_kernel<false>;
+    if (hipError_t e = ensure_dynamic_lds(kfn, lds, ready[ones ? 1 : 0]); e != hipSuccess) return e;
     dim3 grid(((P + WD_BP - 1) / WD_BP) * slices);
     if (ones)
       hipLaunchKernelGGL((wgrad_dma_kernel<true>), grid, dim3(256), lds, s, Pb, ldp, (const bf16*)Qm, ldq, T, P, Q, tps, slab);

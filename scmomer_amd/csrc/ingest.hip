@@ -17,6 +17,10 @@ namespace scm {
 // ------------------------------------------------------------------------------------------
 SCM_DEV long long bin_value(float v, int rule, int limit) {
   if (rule == 0) {                       // S1: x[x > limit] = limit; .long() truncates toward zero
+    // a NaN is no valid expression value: it becomes the most negative integer (what the reference's host-side
+    // .long() yields), and a negative value truncates to a negative token; both are then reported by the embedding
+    // kernel's token check instead of being looked up
+    if (v != v) return (long long)0x8000000000000000ull;
     v = v > (float)limit ? (float)limit : v;
     return (long long)v;
   }
@@ -131,12 +135,9 @@ __global__ __launch_bounds__(64) void orthogonal_omega_kernel(const float* __res
 // ---------------------------------------------------------------- host launchers
 hipError_t bin_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows, int n_rows,
                    int B, int N, int rule, int limit, int64_t* tokens, int* err, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)bin_csr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              BIN_MAX_GENES * (int)sizeof(float));
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> ready;
+  if (hipError_t e = ensure_dynamic_lds((const void*)bin_csr_kernel, BIN_MAX_GENES * sizeof(float), ready); e != hipSuccess)
+    return e;
   Traced tr(K_BIN, 0, s, (double)B * N * 8);
   hipLaunchKernelGGL(bin_csr_kernel, dim3(B), dim3(1024), (size_t)N * sizeof(float), s, indptr, indices, values, rows,
                      n_rows, N, rule, limit, tokens, err);

@@ -164,7 +164,7 @@ SCM_DEV uint32_t lds_addr_of(const void* p) {
 }
 SCM_DEV void dma16_to_lds(u32x4 rsrc, uint32_t lds_wave_base, uint32_t voffset, uint32_t soffset) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_wave_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+               :: "s"(lds_wave_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
 }
 // s_waitcnt vmcnt(N) only (expcnt/lgkmcnt left alone): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4]<<14
 template <int N>

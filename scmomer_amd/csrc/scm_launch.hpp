@@ -2,8 +2,23 @@
 #pragma once
 #include "scm_common.hpp"
 #include "../../include/scmomer_hip.h"
+#include <atomic>
 
 namespace scm {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once on every device
+// the kernel is launched on (bit d of `done` = device d is set up; device numbers fold modulo 64, where a repeat
+// is harmless), from any thread (setting it twice is idempotent), and report a failure to the caller.
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 struct GemmEpi {
   void* out0; long ldo0;
@@ -63,7 +78,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_GEMM_SKINNY = 6,        // gemm_skinny_kernel, + epilogue id (6 consecutive ids)
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
-  K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_BIN, K_OMEGA_QR, K_COUNT
+  K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_BIN, K_OMEGA_QR, K_FEATURE_MAP, K_LINEAR_ATTENTION, K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
@@ -136,5 +151,15 @@ constexpr int CTX_FIN_SCRATCH = NFP * DH + NFP + NFT * SUMS_STRIDE;  // floats p
 hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int nstab,
                               const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s);
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s);
+
+
+// favor_free.hip: the reference's free functions with materialised f32 feature maps
+constexpr int FREE_MAX_FEATURES = 320;
+long feature_map_ws_floats(long BH, int N);
+hipError_t feature_map(const float* data, const float* proj, long BH, int N, int M, int is_query, float normalizer,
+                       float norm_sq, float ratio, float eps, float* out, float* ws, hipStream_t s);
+long linear_attention_ws_floats(long BH, int N, int M);
+hipError_t linear_attention(const float* qf, const float* kf, const float* v, long BH, int N, int M, float* out,
+                            float* ws, hipStream_t s);
 
 }  // namespace scm

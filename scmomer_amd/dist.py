@@ -110,6 +110,34 @@ def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group: Op
             dist.broadcast(t, src=src, group=group)
 
 
+@torch.no_grad()
+def broadcast_projections(performer, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Every replica takes rank `src`'s FAVOR+ projection matrices and redraw counter: one flat broadcast of all
+    FastAttention.projection_matrix buffers plus one of performer.calls_since_last_redraw.  The reference gets the
+    same effect from DistributedDataParallel's buffer broadcast at every forward (s1_pretrain_rna.py:242 with
+    performer_pytorch.py:209,520-534); here it only has to run when the matrices change, i.e. right after a redraw
+    (Performer.redraw_sync).  A no-op without a process group."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    mats = [m.projection_matrix for m in performer.modules() if hasattr(m, "projection_matrix")]
+    if not mats:
+        return
+    gloo = dist.get_backend(group) == "gloo"
+    flat = torch.cat([m.reshape(-1).to(torch.float32) for m in mats])
+    counter = performer.calls_since_last_redraw.reshape(1).clone()
+    if gloo and flat.is_cuda:           # CPU-only backend: stage through host memory
+        flat, counter = flat.cpu(), counter.cpu()
+    dist.broadcast(flat, src=src, group=group)
+    dist.broadcast(counter, src=src, group=group)
+    off = 0
+    for m in mats:
+        m.copy_(flat[off:off + m.numel()].view_as(m))
+        off += m.numel()
+    performer.calls_since_last_redraw.copy_(counter.reshape(()))
+    if hasattr(performer, "_calls_host"):
+        performer._calls_host = None    # the host mirror of the counter is re-read at the next forward
+
+
 def max_over_ranks(seconds: float, device) -> float:
     """Step time of the job = the slowest rank's."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -3,7 +3,8 @@ densified and binned to tokens by one kernel (no per-cell host work, no host->de
 
 Mirrors SCDataset of the S1 script (s1_pretrain_rna.py:127-140: ``data[index].toarray()[0]``, values above
 ``class_limit - 2`` set to it, ``.long()``) and the binning inside scMomer.forward / get_cell_embedding
-(scmomer.py:56,108).  Integer results are bit-identical to the reference's.
+(scmomer.py:56,108).  Values are held as float32 (what the reference's matrices hold); integer results are
+bit-identical to the reference's for float32 input, and float64 input that would bin differently is refused.
 """
 from __future__ import annotations
 
@@ -46,6 +47,15 @@ class DeviceCSR:
         """m: anything scipy.sparse can turn into CSR (the ``.X`` of an AnnData), or a dense 2-D array."""
         import scipy.sparse as sp
         m = sp.csr_matrix(m)
+        if m.data.dtype == np.float64 and m.data.size:
+            # The matrix is kept in float32 on the device, while the reference bins in the matrix's own dtype
+            # (s1_pretrain_rna.py:134-136).  The two agree unless rounding a float64 value to float32 moves it across
+            # an integer (e.g. 2.9999999999 -> 3.0): refuse such a matrix instead of binning a cell differently.
+            d64 = m.data
+            d32 = d64.astype(np.float32).astype(np.float64)
+            if np.any(np.trunc(d64) != np.trunc(d32)) or np.any(np.rint(d64) != np.rint(d32)):
+                raise ValueError("float64 expression values whose float32 rounding crosses an integer boundary: "
+                                 "bins would differ from the reference's; convert the matrix to float32 first")
         return cls(m.indptr, m.indices, m.data, m.shape[1], device)
 
     @property

@@ -83,7 +83,10 @@ def prep_omega(omega: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
 
 
 # ----------------------------------------------------------------------------- embedding
-def embed_fwd(tok: torch.Tensor, emb: torch.Tensor, g2v: Optional[torch.Tensor]) -> torch.Tensor:
+def embed_fwd(tok: torch.Tensor, emb: torch.Tensor, g2v: Optional[torch.Tensor],
+              err: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """err: device int32 scalar the caller owns; the kernel sets it to 1 when a token id is outside [0, V) (such a
+    token is looked up as token 0) and never clears it.  Without one a fresh flag is attached to the result."""
     _req(tok, torch.int64, "tokens")
     _req(emb, F32, "token_emb.weight")
     b, n = tok.shape
@@ -93,9 +96,12 @@ def embed_fwd(tok: torch.Tensor, emb: torch.Tensor, g2v: Optional[torch.Tensor])
         if g2v.shape[0] < n or g2v.shape[1] != d:
             raise ValueError("positional table too small")
     out = torch.empty((b, n, d), dtype=F32, device=tok.device)
-    err = torch.zeros(1, dtype=torch.int32, device=tok.device)
+    if err is None:
+        err = torch.zeros(1, dtype=torch.int32, device=tok.device)
+    else:
+        _req(err, torch.int32, "err")
     check(lib.scm_embed_fwd(_p(tok), _p(emb), _p(g2v), b, n, d, v, _p(out), _p(err), _stream()), "scm_embed_fwd")
-    out._scm_err = err  # checked lazily by the caller (no sync here)
+    out._scm_err = err  # read by the caller where it synchronises anyway (no sync here)
     return out
 
 
@@ -217,6 +223,44 @@ def favor_bwd(q, k, v, o_centered, dout, omega_b, sv: FavorSaved, dq, dk, dv):
                             _p(sv.ctx), _p(sv.z), _p(sv.sums), _p(sv.rowmax), _p(sv.den), _p(sv.kmax),
                             _p(sv.kmax_idx), view4(dq), view4(dk), view4(dv), _p(dctx), _p(dz), _p(dsums), _p(dden), _p(ws),
                             _stream()), "scm_favor_bwd")
+
+
+# ----------------------------------------------------------------------------- free functions (materialised, f32)
+def feature_map(data: torch.Tensor, projection: torch.Tensor, is_query: bool, normalize_data: bool = True,
+                eps: float = 1e-4) -> torch.Tensor:
+    """softmax_kernel on the device: data f32 [..., N, 64] contiguous, projection f32 [M, 64] -> f32 [..., N, M]."""
+    _req(data, F32, "data")
+    _req(projection, F32, "projection_matrix")
+    if data.shape[-1] != DIM_HEAD or projection.dim() != 2 or projection.shape[1] != DIM_HEAD:
+        raise NotImplementedError(f"the MI355X kernels are built for a head dimension of 64 (got data "
+                                  f"{tuple(data.shape)}, projection {tuple(projection.shape)})")
+    n, m = data.shape[-2], projection.shape[0]
+    bh = data.numel() // (n * DIM_HEAD) if data.numel() else 0
+    out = torch.empty((*data.shape[:-1], m), dtype=F32, device=data.device)
+    if out.numel() == 0:
+        return out
+    ws = None if is_query else torch.empty(lib.scm_feature_map_ws_floats(bh, n), dtype=F32, device=data.device)
+    check(lib.scm_feature_map(_p(data), _p(projection), bh, n, m, int(bool(is_query)), int(bool(normalize_data)),
+                              float(eps), _p(out), _p(ws), _stream()), "scm_feature_map")
+    return out
+
+
+def linear_attention(qf: torch.Tensor, kf: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """linear_attention on the device: q', k' f32 [..., N, M], v f32 [..., N, 64] -> f32 [..., N, 64]."""
+    for t, nm in ((qf, "q"), (kf, "k"), (v, "v")):
+        _req(t, F32, nm)
+    if v.shape[-1] != DIM_HEAD or qf.shape != kf.shape or qf.shape[:-1] != v.shape[:-1]:
+        raise NotImplementedError(f"expected q, k [..., N, M] and v [..., N, 64] (got {tuple(qf.shape)}, "
+                                  f"{tuple(kf.shape)}, {tuple(v.shape)})")
+    n, m = qf.shape[-2], qf.shape[-1]
+    bh = v.numel() // (n * DIM_HEAD) if v.numel() else 0
+    out = torch.empty(v.shape, dtype=F32, device=v.device)
+    if out.numel() == 0:
+        return out
+    ws = torch.empty(lib.scm_linear_attention_ws_floats(bh, n, m), dtype=F32, device=v.device)
+    check(lib.scm_linear_attention(_p(qf), _p(kf), _p(v), bh, n, m, _p(out), _p(ws), _stream()),
+          "scm_linear_attention")
+    return out
 
 
 # ----------------------------------------------------------------------------- final norm + head

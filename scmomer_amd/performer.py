@@ -132,6 +132,41 @@ def redraw_projection_matrices(fast_attentions, device) -> None:
 
 
 # --------------------------------------------------------------------------------------------
+# the reference's free functions (performer_pytorch.py:67-92,144-149): materialised feature maps in f32
+# --------------------------------------------------------------------------------------------
+def _no_grad_path(name, *tensors):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            f"{name} materialises the feature maps and is forward-only on the MI355X kernels; the differentiable "
+            "attention is FastAttention (fused forward and backward, feature maps never written to memory)")
+
+
+def softmax_kernel(data, *, projection_matrix, is_query, normalize_data=True, eps=1e-4, device=None):
+    """performer_pytorch.py:67-92 on the device, exact f32 arithmetic: data [b, h, n, 64], projection_matrix
+    [m, 64] -> [b, h, n, m] in data's dtype.  Queries are stabilised by their own row max, keys by ONE max over
+    the whole tensor (:89-90).  `device` is accepted for signature compatibility (the result lives on data's
+    device, as in the reference)."""
+    _no_grad_path("softmax_kernel", data, projection_matrix)
+    if not data.is_cuda:
+        raise RuntimeError("softmax_kernel runs on the MI355X kernels only: pass device tensors")
+    out = ops.feature_map(data.detach().to(F32).contiguous(),
+                          projection_matrix.detach().to(device=data.device, dtype=F32).contiguous(),
+                          bool(is_query), bool(normalize_data), float(eps))
+    return out.to(data.dtype)
+
+
+def linear_attention(q, k, v):
+    """performer_pytorch.py:144-149 on the device, exact f32 arithmetic: feature-mapped q, k [b, h, n, m] and
+    v [b, h, n, 64] -> [b, h, n, 64]."""
+    _no_grad_path("linear_attention", q, k, v)
+    if not q.is_cuda:
+        raise RuntimeError("linear_attention runs on the MI355X kernels only: pass device tensors")
+    out = ops.linear_attention(q.detach().to(F32).contiguous(), k.detach().to(F32).contiguous(),
+                               v.detach().to(F32).contiguous())
+    return out.to(v.dtype)
+
+
+# --------------------------------------------------------------------------------------------
 # FAVOR+ attention as a standalone autograd op: FastAttention.forward, performer_pytorch.py:233-250
 # --------------------------------------------------------------------------------------------
 def _as_bf16_bhnd(t: torch.Tensor) -> torch.Tensor:
@@ -286,18 +321,6 @@ class SelfAttention(nn.Module):
         return self_attention_forward(self, x)
 
 
-def route_args(router, args, depth):
-    """reversible.py:8-17"""
-    routed_args = [(dict(), dict()) for _ in range(depth)]
-    matched_keys = [key for key in args.keys() if key in router]
-    for key in matched_keys:
-        val = args[key]
-        for d, ((f_args, g_args), routes) in enumerate(zip(routed_args, router[key])):
-            new_f_args, new_g_args = map(lambda route: ({key: val} if route else {}), routes)
-            routed_args[d] = ({**f_args, **new_f_args}, {**g_args, **new_g_args})
-    return routed_args
-
-
 class SequentialSequence(nn.Module):
     """reversible.py:126-151: x = x + f(x); x = x + g(x) per layer."""
 
@@ -310,11 +333,12 @@ class SequentialSequence(nn.Module):
 
     def forward(self, x, output_attentions=False, **kwargs):
         _unsupported("output_attentions", output_attentions, False)
-        args = route_args(self.args_route, kwargs, len(self.layers))
-        for (f, g), (f_args, g_args) in zip(self.layers, args):
-            f_args = {k: v for k, v in f_args.items() if exists(v)}
-            x = x + f(x, **f_args)
-            x = x + g(x, **g_args)
+        for name, val in kwargs.items():          # the routed keywords (mask, pos_emb) are None on this path
+            if exists(val):
+                raise NotImplementedError(f"argument {name} is not used on the scMomer path")
+        for f, g in self.layers:
+            x = x + f(x)
+            x = x + g(x)
         return x
 
 
@@ -353,6 +377,10 @@ class Performer(nn.Module):
         self.feature_redraw_interval = feature_redraw_interval
         self.register_buffer("calls_since_last_redraw", torch.tensor(0))
         self._calls_host = None
+        # called with this module right after a redraw.  Data-parallel drivers put a broadcast of rank 0's matrices
+        # here: under the reference's DistributedDataParallel the buffer broadcast at every forward does that
+        # (s1_pretrain_rna.py:242), so every replica keeps rank 0's draw.
+        self.redraw_sync = None
 
     def fix_projection_matrices_(self):
         self.feature_redraw_interval = None
@@ -379,6 +407,8 @@ class Performer(nn.Module):
             redraw_projection_matrices(find_modules(self, FastAttention), device)
             self.calls_since_last_redraw.zero_()
             self._calls_host = 0
+            if self.redraw_sync is not None:
+                self.redraw_sync(self)
             return
         self.calls_since_last_redraw += 1
         if self._calls_host is not None:
@@ -450,6 +480,20 @@ class PerformerLM(nn.Module):
 
     def fix_projection_matrices_(self):
         self.performer.fix_projection_matrices_()
+
+    def raise_on_bad_token(self):
+        """The reference's nn.Embedding faults on a token id outside [0, num_tokens) (performer_pytorch.py:604).
+        The embedding kernel cannot raise from the device: it looks such a token up as token 0 and sets a flag.
+        This call reads the flag (it synchronises with the device: use it where the host waits anyway, e.g. at the
+        end of an epoch), clears it and raises IndexError when any forward since the last check saw a bad id."""
+        bad = False
+        for flag in self.__dict__.get("_scm_token_err", {}).values():
+            if int(flag.item()):
+                flag.zero_()
+                bad = True
+        if bad:
+            raise IndexError(f"token id outside [0, {self.token_emb.num_embeddings}) reached the embedding "
+                             "(negative or NaN expression values, or a wrong class_limit)")
 
     def forward(self, x, return_encodings=False, output_attentions=False, **kwargs):
         b, n = x.shape

@@ -10,6 +10,7 @@ and 128/256-wide LayerNorms, left to torch.  The ATAC branch (a ViT) is not part
 import torch
 import torch.nn as nn
 
+from . import ingest
 from .rna_encoder import Performer
 
 
@@ -58,7 +59,7 @@ class scMomer(nn.Module):
             if mode == 'multimodal':
                 raise NotImplementedError("mode='multimodal' needs the ATAC encoder, which is outside this path")
             raise ValueError(f"Unknown mode: {mode}")
-        rna_long = torch.round(rna_values).long().clamp(min=0, max=5)
+        rna_long = ingest.bin_cells(rna_values, ingest.RULE_SCMOMER, 5)   # round half to even, clamp to [0, 5]
         rna_embeds = self.rna_ln(self._get_rna_features(rna_long))
         atac_embeds = self.encoder(rna_values)
         out = self.to_out(torch.cat([atac_embeds, rna_embeds], 1))
@@ -68,7 +69,7 @@ class scMomer(nn.Module):
 
     def get_cell_embedding(self, rna_values):
         """scmomer.py:96-113 -> [batch, 128]"""
-        rna_long = torch.round(rna_values).long().clamp(min=0, max=5)
+        rna_long = ingest.bin_cells(rna_values, ingest.RULE_SCMOMER, 5)   # round half to even, clamp to [0, 5]
         rna_embeds = self.rna_ln(self._get_rna_features(rna_long))
         atac_embeds = self.encoder(rna_values)
         return self.to_out(torch.cat([atac_embeds, rna_embeds], 1))

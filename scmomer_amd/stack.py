@@ -363,6 +363,7 @@ class StackSpec:
     head_b: Optional[torch.Tensor] = None
     head_relu: bool = False
     head_out_shape: Optional[str] = None     # 'linear' | 'conv' | None (encodings only)
+    token_err: Optional[torch.Tensor] = None  # device int32 [1]: set by the embedding kernel on a bad token id
     save: bool = True
 
 
@@ -388,8 +389,7 @@ class _StackFn(torch.autograd.Function):
         tapes = []
         if spec.token_emb is not None:
             tokens = inp
-            x = ops.embed_fwd(tokens.contiguous(), spec.token_emb.detach(), spec.pos_table)
-            ctx.embed_err = x._scm_err
+            x = ops.embed_fwd(tokens.contiguous(), spec.token_emb.detach(), spec.pos_table, spec.token_err)
         else:
             tokens = None
             x = inp.to(F32).contiguous()
@@ -519,6 +519,16 @@ def _head_kind(to_out, dim: int):
     return None
 
 
+def token_error_flag(model, device) -> torch.Tensor:
+    """The model's bad-token flag on `device` (created on first use, one per device): every forward ORs into it
+    without synchronising; PerformerLM.raise_on_bad_token reads and clears it."""
+    flags = model.__dict__.setdefault("_scm_token_err", {})
+    key = (device.type, device.index)
+    if key not in flags:
+        flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return flags[key]
+
+
 def run_model(model, tokens: torch.Tensor, return_encodings: bool):
     """PerformerLM.forward on the fused stack."""
     if tokens.dtype != torch.int64:
@@ -527,6 +537,7 @@ def run_model(model, tokens: torch.Tensor, return_encodings: bool):
     grad_on = torch.is_grad_enabled()
     spec = _build_spec(model, model.performer.net.layers, save=grad_on)
     spec.token_emb = model.token_emb.weight
+    spec.token_err = token_error_flag(model, tokens.device)
     spec.names.insert(0, (-1, "token_emb"))
     pos = getattr(model.pos_emb, "emb", None)
     spec.pos_table = pos.weight.detach() if pos is not None else None

@@ -221,6 +221,11 @@ class S1Trainer:
         # the accumulators ARE the slices of the all-reduce bucket: the exchange needs no gather/scatter copies
         self.accs = list(self.averager.views) if self.averager is not None else []
         sdist.broadcast_parameters(list(model.parameters()) + list(model.buffers()), src=0, group=group)
+        # replicas must keep sharing ONE set of projection matrices when the model redraws them (every
+        # feature_redraw_interval forward calls in train mode): rank 0's draw wins, as under the reference's DDP
+        performer = getattr(model, "performer", None)
+        if performer is not None and self.world > 1:
+            performer.redraw_sync = lambda perf: sdist.broadcast_projections(perf, src=0, group=group)
         self.index = 0                                       # micro-steps since the start of the epoch
         self.use_graph = use_graph
         self._graph = None
@@ -343,6 +348,13 @@ class S1Trainer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return float(t.item()) / self.world
 
+    def _check_tokens(self) -> None:
+        """Bad token ids seen by the embedding kernel since the last check raise here, where the host has just
+        waited for the device anyway."""
+        check = getattr(self.model, "raise_on_bad_token", None)
+        if check is not None:
+            check()
+
     def train_epoch(self, batches: Iterable[torch.Tensor]) -> Tuple[float, float]:
         """s1_pretrain_rna.py:281-322 for one epoch.  -> (training loss as the reference prints it, i.e. the mean
         of loss / grad_acc times grad_acc; accuracy in percent), both averaged over the ranks; then one
@@ -360,6 +372,7 @@ class S1Trainer:
             raise ValueError("empty epoch")
         epoch_loss = self._mean_over_ranks(running_loss / n)
         epoch_acc = self._mean_over_ranks(100 * running_acc / n)
+        self._check_tokens()
         self.scheduler.step()
         return epoch_loss * self.grad_acc, epoch_acc
 
@@ -385,6 +398,7 @@ class S1Trainer:
         if n == 0:
             raise ValueError("empty validation set")
         val_loss = self._mean_over_ranks(running / n)
+        self._check_tokens()
         per_cell = torch.stack([torch.cat(correct), torch.cat(counted)], dim=1)      # [cells of this rank, 2]
         if self.world > 1:
             if per_cell.is_cuda and dist.get_backend(self.group) == "gloo":

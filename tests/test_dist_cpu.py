@@ -116,3 +116,54 @@ def test_single_process_is_a_no_op():
     for b, p in zip(before, model.parameters()):
         assert torch.equal(b, p.grad)
     assert sdist.max_over_ranks(2.5, "cpu") == 2.5
+
+
+def _redraw_worker(rank, world, port, out_dir):
+    """Each rank owns a replica whose generator is seeded differently; after a redraw every replica must hold
+    rank 0's matrices (what DDP's buffer broadcast guarantees in the reference, s1_pretrain_rna.py:242)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from scmomer_amd import performer as P
+        from scmomer_amd import train
+
+        class Wrap(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.performer = P.Performer(200, 2, 10, 64, feature_redraw_interval=3, qkv_bias=False)
+
+        torch.manual_seed(100 + rank)                   # replicas start with DIFFERENT projections
+        model = Wrap()
+        trainer = train.S1Trainer(model, grad_acc=1)    # construction replicates rank 0's weights and buffers
+        perf = model.performer
+        before = [m.projection_matrix.clone() for m in perf.modules() if hasattr(m, "projection_matrix")]
+        model.train()
+        torch.manual_seed(200 + rank)                   # ... and would draw DIFFERENT new ones
+        for _ in range(3):
+            perf.check_redraw_projections()             # ticks 0 -> 3
+        assert int(perf.calls_since_last_redraw) == 3
+        perf.check_redraw_projections()                 # redraw + broadcast from rank 0
+        after = [m.projection_matrix.clone() for m in perf.modules() if hasattr(m, "projection_matrix")]
+        torch.save({"before": before, "after": after, "calls": int(perf.calls_since_last_redraw)},
+                   os.path.join(out_dir, f"omega{rank}.pt"))
+        assert trainer.world == world
+    finally:
+        dist.destroy_process_group()
+
+
+def test_redrawn_projections_stay_identical_across_ranks(tmp_path):
+    world = 2
+    mp.spawn(_redraw_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "omega0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "omega1.pt"))
+    assert r0["calls"] == 0 and r1["calls"] == 0
+    assert len(r0["after"]) == 2
+    for a0, a1, b0, b1 in zip(r0["after"], r1["after"], r0["before"], r1["before"]):
+        assert torch.equal(b0, b1)                      # replicated at construction
+        assert torch.equal(a0, a1)                      # and again after the redraw: rank 0's draw everywhere
+        assert not torch.equal(a0, b0)                  # the redraw did happen
+    # rank 0's draw is what a single process with rank 0's seed draws
+    from scmomer_amd import performer as P
+    torch.manual_seed(200)
+    want = P.gaussian_orthogonal_random_matrix(266, 64)
+    assert torch.equal(r1["after"][0], want)

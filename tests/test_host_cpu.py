@@ -8,17 +8,16 @@ import pytest
 import torch
 
 import scmomer_amd as S
-from scmomer_amd import s1
 from oracle import masking_oracle as MO
 
 
 def test_bins_and_mask_bit_exact_vs_reference_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, "mask_bin.npz"))
     cells = torch.from_numpy(g["cells"])
-    assert torch.equal(s1.bin_s1(cells), torch.from_numpy(g["s1_bins"]))
-    assert torch.equal(s1.bin_scmomer(cells), torch.from_numpy(g["scmomer_bins"]))
+    assert torch.equal(MO.bin_s1_tensor(cells), torch.from_numpy(g["s1_bins"]))
+    assert torch.equal(MO.bin_scmomer_tensor(cells), torch.from_numpy(g["scmomer_bins"]))
     tok = torch.from_numpy(g["s1_bins"])
-    mi, lab = s1.data_mask(tok, 0.15, 0.9, 6, 6, rand_pick=torch.from_numpy(g["rand_pick"]),
+    mi, lab = MO.data_mask_tensor(tok, 0.15, 0.9, 6, 6, rand_pick=torch.from_numpy(g["rand_pick"]),
                            rand_replace=torch.from_numpy(g["rand_replace"]))
     assert torch.equal(mi, torch.from_numpy(g["masked_input"]))
     assert torch.equal(lab, torch.from_numpy(g["labels"]))
@@ -26,8 +25,8 @@ def test_bins_and_mask_bit_exact_vs_reference_fixture(golden_dir):
 
 def test_bin_edge_values():
     x = torch.tensor([[0.5, 1.5, 2.5, 5.6, -0.2, 4.999, 5.0, 7.3, 0.0]])
-    assert s1.bin_scmomer(x).tolist() == [[0, 2, 2, 5, 0, 5, 5, 5, 0]]       # half-to-even, clamp
-    assert s1.bin_s1(x).tolist() == [[0, 1, 2, 5, 0, 4, 5, 5, 0]]            # cap at 5, truncate
+    assert MO.bin_scmomer_tensor(x).tolist() == [[0, 2, 2, 5, 0, 5, 5, 5, 0]]       # half-to-even, clamp
+    assert MO.bin_s1_tensor(x).tolist() == [[0, 1, 2, 5, 0, 4, 5, 5, 0]]            # cap at 5, truncate
 
 
 @pytest.mark.parametrize("seed,n", [(0, 64), (1, 257), (2, 2000), (3, 16906)])
@@ -36,10 +35,10 @@ def test_mask_matches_oracle_on_random_rows(seed, n):
     cells = ((rng.random((3, n)) < 0.15) * rng.gamma(2.0, 1.2, (3, n))).astype(np.float32)
     if seed == 1:
         cells[1] = 0.0                      # a cell with no expressed gene: nothing to mask
-    tok = s1.bin_s1(torch.from_numpy(cells))
+    tok = MO.bin_s1_tensor(torch.from_numpy(cells))
     rp = rng.random((3, n), dtype=np.float32)
     rr = rng.random((3, n), dtype=np.float32)
-    mi, lab = s1.data_mask(tok, 0.15, 0.9, 6, 6, rand_pick=torch.from_numpy(rp), rand_replace=torch.from_numpy(rr))
+    mi, lab = MO.data_mask_tensor(tok, 0.15, 0.9, 6, 6, rand_pick=torch.from_numpy(rp), rand_replace=torch.from_numpy(rr))
     omi, olab = MO.data_mask(tok.numpy(), 0.15, 0.9, 6, 6, rp, rr)
     assert np.array_equal(mi.numpy(), omi) and np.array_equal(lab.numpy(), olab)
     # size-independent properties: exactly ceil(0.15 * nnz) positions picked per row, never a 0 token

@@ -12,7 +12,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import performer_oracle as O
-from scmomer_amd import s1, train
+from oracle import masking_oracle as MO
+from scmomer_amd import train
 
 
 def _torch_loss(logits, labels, pad_id):
@@ -20,7 +21,7 @@ def _torch_loss(logits, labels, pad_id):
 
 
 def _trainer(model, g, **kw):
-    return train.S1Trainer(model, learning_rate=float(g["lr"]), grad_acc=int(g["grad_acc"]), mask_fn=s1.data_mask,
+    return train.S1Trainer(model, learning_rate=float(g["lr"]), grad_acc=int(g["grad_acc"]), mask_fn=MO.data_mask_tensor,
                            loss_fn=_torch_loss, **kw)
 
 
@@ -134,7 +135,7 @@ def test_unfinished_accumulation_window_carries_over(g):
 def test_early_stopping(g, tmp_path):
     tok = O.standin_cells(7, 6, 32)
     model = O.standin_lm(99)
-    tr = train.S1Trainer(model, learning_rate=0.0, grad_acc=1, mask_fn=s1.data_mask, loss_fn=_torch_loss)
+    tr = train.S1Trainer(model, learning_rate=0.0, grad_acc=1, mask_fn=MO.data_mask_tensor, loss_fn=_torch_loss)
     seq = iter([1.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0])
     tr.validate = lambda batches, n=None: (next(seq), 50.0)
     logs = []
@@ -176,7 +177,7 @@ def _worker(rank, world, port, out_dir, lr, grad_acc):
 def _fixed_mask(data, mask_prob, replace_prob, pad_id, mask_id):
     """draws that depend only on the cells, so that one process and two ranks mask identically"""
     gen = torch.Generator().manual_seed(int(data.sum()) + 17 * data.shape[0])
-    return s1.data_mask(data, mask_prob, replace_prob, pad_id, mask_id, rand_pick=torch.rand(data.shape, generator=gen),
+    return MO.data_mask_tensor(data, mask_prob, replace_prob, pad_id, mask_id, rand_pick=torch.rand(data.shape, generator=gen),
                         rand_replace=torch.rand(data.shape, generator=gen))
 
 
