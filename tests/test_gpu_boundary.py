@@ -1,0 +1,221 @@
+"""GPU parity of the module-level API surface that the reference exposes besides PerformerLM.forward
+(performer_pytorch.py:67-92,144-149,198-264,289-331,366-406,536-539): the free functions softmax_kernel and
+linear_attention (f32 kernels: rtol 1e-3 against the reference's own outputs), FastAttention used on its own
+(forward and backward against the reference's fixture), PreLayerNorm / SelfAttention / FeedForward / Performer
+called directly (forward and backward against the CPU oracle), and the bad-token report of the embedding.
+Tolerances: parity_util (elementwise bf16 bound) for the bf16 paths."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import performer_oracle as O
+from parity_util import ATOL_RMS_ACT, ATOL_RMS_GRAD, margin, rell2, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def S():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import scmomer_amd
+    return scmomer_amd
+
+
+# ------------------------------------------------------------------------------------------------ free functions
+def test_free_functions_match_reference_fixture(S, golden_dir):
+    """softmax_kernel (query and key modes) and linear_attention against the reference's own f32 outputs:
+    rtol 1e-3 (measured ~1e-6: same f32 arithmetic, different summation order)."""
+    g = np.load(os.path.join(golden_dir, "feature_map.npz"))
+    data, v, _, _ = O.attention_inputs(int(g["seed"]), tuple(g["shape"]), float(g["scale"]))
+    proj = torch.from_numpy(g["proj"]).to(DEV)
+    qf = S.softmax_kernel(data.to(DEV), projection_matrix=proj, is_query=True)
+    kf = S.softmax_kernel(data.to(DEV), projection_matrix=proj, is_query=False)
+    assert qf.shape == tuple(g["q_features"].shape) and qf.dtype == torch.float32
+    np.testing.assert_allclose(qf.cpu().numpy(), g["q_features"], rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(kf.cpu().numpy(), g["k_features"], rtol=1e-3, atol=1e-9)
+    la = S.linear_attention(qf, kf, v.to(DEV))
+    np.testing.assert_allclose(la.cpu().numpy(), g["linear_attention"], rtol=1e-3, atol=1e-5)
+    print("softmax_kernel q/k max rel err",
+          float(np.abs(qf.cpu().numpy() / g["q_features"] - 1).max()),
+          float(np.abs(kf.cpu().numpy() / g["k_features"] - 1).max()),
+          "linear_attention rel L2", rell2(la, g["linear_attention"]))
+
+
+@pytest.mark.parametrize("b,h,n,m,seed", [(1, 1, 1, 266, 0), (2, 3, 33, 266, 1), (1, 2, 1000, 266, 2), (3, 1, 257, 64, 3),
+                                          (1, 1, 70, 320, 4)])
+def test_free_functions_match_oracle_on_ragged_sizes(S, b, h, n, m, seed):
+    q, k, v, _ = O.attention_inputs(seed, (b, h, n, 64), 1.3)
+    gen = torch.Generator().manual_seed(seed)
+    proj = torch.randn((m, 64), generator=gen) * (1.0 if seed % 2 else 3.0)
+    for is_query, x in ((True, q), (False, k)):
+        for normalize in (True, False):
+            d = S.softmax_kernel(x.to(DEV), projection_matrix=proj.to(DEV), is_query=is_query,
+                                 normalize_data=normalize, eps=1e-4 if normalize else 1e-3)
+            c = (64 ** -0.25) if normalize else 1.0
+            s = (c * x) @ proj.t()
+            diag = (x * x).sum(-1, keepdim=True) / 2.0 * (c ** 2)
+            stab = s.amax(-1, keepdim=True) if is_query else s.max()
+            want = (m ** -0.5) * (torch.exp(s - diag - stab) + (1e-4 if normalize else 1e-3))
+            torch.testing.assert_close(d.cpu(), want, rtol=1e-3, atol=1e-9)
+    qf, kf = O.softmax_kernel(q, proj, True), O.softmax_kernel(k, proj, False)
+    la = S.linear_attention(qf.to(DEV), kf.to(DEV), v.to(DEV))
+    torch.testing.assert_close(la.cpu(), O.linear_attention(qf, kf, v), rtol=1e-3, atol=1e-5)
+
+
+def test_free_functions_reject_what_they_cannot_do(S):
+    x = torch.randn(1, 1, 8, 64, device=DEV)
+    proj = torch.randn(266, 64, device=DEV)
+    with pytest.raises(NotImplementedError):
+        S.softmax_kernel(x.requires_grad_(), projection_matrix=proj, is_query=True)      # forward-only
+    with pytest.raises(NotImplementedError):
+        S.softmax_kernel(torch.randn(1, 1, 8, 32, device=DEV), projection_matrix=torch.randn(266, 32, device=DEV),
+                         is_query=True)
+    with pytest.raises(Exception):
+        S.softmax_kernel(x.detach(), projection_matrix=torch.randn(400, 64, device=DEV), is_query=True)
+    with pytest.raises(RuntimeError):
+        S.softmax_kernel(x.detach().cpu(), projection_matrix=proj.cpu(), is_query=True)
+
+
+# ------------------------------------------------------------------------------------------------ FastAttention
+def test_fast_attention_module_vs_reference_fixture(S, golden_dir):
+    """FastAttention(64)(q, k, v) forward and backward against the reference's own output and input gradients."""
+    g = np.load(os.path.join(golden_dir, "fast_attention.npz"))
+    q, k, v, cot = O.attention_inputs(int(g["seed"]), tuple(g["shape"]), float(g["scale"]))
+    fa = S.FastAttention(64)
+    fa.projection_matrix.copy_(torch.from_numpy(g["proj"]))
+    fa = fa.to(DEV)
+    qd, kd, vd = (t.to(DEV).requires_grad_() for t in (q, k, v))
+    out = fa(qd, kd, vd)
+    assert out.dtype == torch.float32 and out.shape == q.shape
+    (out * cot.to(DEV)).sum().backward()
+    m_out, _, _ = report("FastAttention out", out, g["out"])
+    assert m_out <= ATOL_RMS_ACT
+    for name, got in (("dq", qd.grad), ("dk", kd.grad), ("dv", vd.grad)):
+        m_, _, _ = report("FastAttention " + name, got, g[name])
+        assert m_ <= ATOL_RMS_GRAD, name
+    with torch.no_grad():                                   # a second call, no tape
+        again = fa(qd.detach(), kd.detach(), vd.detach())
+    assert torch.equal(again, out.detach())
+
+
+# ------------------------------------------------------------------------------------------------ layer modules
+def _lm(S, p, n, depth):
+    m = S.PerformerLM(num_tokens=7, dim=200, depth=depth, max_seq_len=n, heads=10, local_attn_heads=0,
+                      g2v_position_emb=True)
+    m.load_state_dict(p, strict=True)
+    m.fix_projection_matrices_()
+    return m.to(DEV).train()
+
+
+def _leaves(p, prefix):
+    keys = [k for k, v in p.items() if k.startswith(prefix) and v.dtype == torch.float32
+            and not k.endswith("projection_matrix")]
+    return {k: p[k].clone().requires_grad_() for k in keys}
+
+
+def _check_grads(module_params, leaves, prefix, what):
+    worst = 0.0
+    for k, leaf in leaves.items():
+        got = module_params[k[len(prefix):]].grad
+        assert got is not None, k
+        m_ = margin(got, leaf.grad)
+        worst = max(worst, m_)
+        assert m_ <= ATOL_RMS_GRAD, f"{what} {k}: margin {m_:.3e}"
+    print(f"{what}: {len(leaves)} parameter gradients, worst elementwise margin {worst:.3e} x rms")
+
+
+@pytest.mark.parametrize("n,bsz", [(300, 2), (77, 1)])
+def test_layer_modules_called_directly_vs_oracle(S, n, bsz):
+    """layers[i][0](x) (PreLayerNorm(SelfAttention)), layers[i][1](x) (PreLayerNorm(Chunk(FeedForward))), the bare
+    SelfAttention and FeedForward inside them, and model.performer(x): forward, input gradient and parameter
+    gradients against autograd over the CPU oracle."""
+    depth = 2
+    p = O.make_params(41, depth=depth, max_seq_len=n)
+    model = _lm(S, p, n, depth)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((bsz, n, 200)).astype(np.float32))
+    cot = torch.from_numpy(rng.standard_normal((bsz, n, 200)).astype(np.float32))
+
+    def run(module, prefix, oracle_fn, what):
+        module.zero_grad(set_to_none=True)
+        xd = x.to(DEV).requires_grad_()
+        y = module(xd)
+        (y * cot.to(DEV)).sum().backward()
+        leaves = _leaves(p, prefix)
+        pp = dict(p)
+        pp.update(leaves)
+        xo = x.clone().requires_grad_()
+        yo = oracle_fn(xo, pp)
+        (yo * cot).sum().backward()
+        m_y, _, _ = report(what + " out", y, yo)
+        m_x, _, _ = report(what + " dx", xd.grad, xo.grad)
+        assert m_y <= ATOL_RMS_ACT and m_x <= ATOL_RMS_GRAD, what
+        _check_grads(dict(module.named_parameters()), leaves, prefix, what)
+
+    layers = model.performer.net.layers
+    a = "performer.net.layers.1.0."
+    f = "performer.net.layers.0.1."
+    run(layers[1][0], a, lambda t, pp: O.self_attention(t, pp, a, 10), "PreLayerNorm(SelfAttention)")
+    run(layers[0][1], f, lambda t, pp: O.feed_forward(t, pp, f), "PreLayerNorm(FeedForward)")
+
+    def bare_attention(t, pp):
+        b_, n_, _ = t.shape
+        split = lambda z: z.reshape(b_, n_, 10, 64).permute(0, 2, 1, 3)
+        q, k, v = (t @ pp[a + f"fn.to_{c}.weight"].t() for c in "qkv")
+        o = O.favor_attention(split(q), split(k), split(v), pp[a + "fn.fast_attention.projection_matrix"])
+        return o.permute(0, 2, 1, 3).reshape(b_, n_, 640) @ pp[a + "fn.to_out.weight"].t() + pp[a + "fn.to_out.bias"]
+
+    def bare_ffn(t, pp):
+        h = O.gelu_erf(t @ pp[f + "fn.fn.w1.weight"].t() + pp[f + "fn.fn.w1.bias"])
+        return h @ pp[f + "fn.fn.w2.weight"].t() + pp[f + "fn.fn.w2.bias"]
+
+    run(layers[1][0].fn, a + "fn.", bare_attention, "SelfAttention")
+    run(layers[0][1].fn.fn, f + "fn.fn.", bare_ffn, "FeedForward")
+
+    def stack_oracle(t, pp):
+        for i in range(depth):
+            t = t + O.self_attention(t, pp, f"performer.net.layers.{i}.0.", 10)
+            t = t + O.feed_forward(t, pp, f"performer.net.layers.{i}.1.")
+        return t
+
+    run(model.performer, "performer.", stack_oracle, "Performer")
+    run(model.performer.net, "performer.net.", stack_oracle, "SequentialSequence")
+
+
+def test_performer_forward_ticks_the_redraw_counter(S):
+    """Performer.forward called directly keeps the reference's bookkeeping (performer_pytorch.py:536-539)."""
+    n = 64
+    m = S.PerformerLM(num_tokens=7, dim=200, depth=1, max_seq_len=n, heads=10, local_attn_heads=0,
+                      g2v_position_emb=False).to(DEV).train()
+    x = torch.randn(1, n, 200, device=DEV)
+    m.performer(x)
+    m.performer(x)
+    assert int(m.performer.calls_since_last_redraw) == 2
+    m.eval()
+    m.performer(x)
+    assert int(m.performer.calls_since_last_redraw) == 2
+
+
+# ------------------------------------------------------------------------------------------------ bad token ids
+def test_bad_token_ids_are_reported(S):
+    """nn.Embedding of the reference raises on a token outside [0, num_tokens) (performer_pytorch.py:604); here
+    the kernel flags it and raise_on_bad_token() reports it at the caller's next synchronisation point."""
+    n = 40
+    m = S.PerformerLM(num_tokens=7, dim=200, depth=1, max_seq_len=n, heads=10, local_attn_heads=0).to(DEV).eval()
+    good = torch.randint(0, 7, (2, n), device=DEV)
+    with torch.no_grad():
+        m(good)
+    m.raise_on_bad_token()                                   # nothing to report
+    for bad_value in (7, -1):
+        bad = good.clone()
+        bad[1, 3] = bad_value
+        with torch.no_grad():
+            m(bad)
+            m(good)                                          # the flag survives later clean batches
+        with pytest.raises(IndexError):
+            m.raise_on_bad_token()
+        m.raise_on_bad_token()                               # cleared by the report

@@ -305,3 +305,61 @@ def test_scmomer_celltype_finetune_partial_backward_vs_oracle():
     for k, q in got.items():
         if ".layers.5." in k or ".layers.0." in k or k.startswith("encoder.") or "token_emb" in k:
             assert q.grad is None, k
+
+
+def test_full_size_config2_forward_backward_vs_oracle():
+    """The benchmarked configuration itself: 3 cells x 16,906 gene tokens, depth 6, train mode, the S1 step's
+    masking (kernel, seeded draws), masked cross entropy (kernel) and the FULL backward, against autograd over the
+    float32 CPU oracle on the same masked tokens and labels: logits, loss and EVERY parameter gradient, per-tensor
+    measures printed.  About 40 s and 24 GB of host memory for the oracle."""
+    from oracle import masking_oracle as MO
+    from parity_util import ATOL_RMS_ACT, ATOL_RMS_GRAD, margin
+    from scmomer_amd import s1
+    n, depth, bsz = 16906, 6, 3
+    p = O.make_params(2024, depth=depth, max_seq_len=n)
+    cells = O.synthetic_cells(2025, bsz, n)
+    tokens = torch.from_numpy(np.minimum(cells, 5).astype(np.int64))
+    gen = torch.Generator().manual_seed(3)
+    pick, rep = torch.rand((bsz, n), generator=gen), torch.rand((bsz, n), generator=gen)
+    m = build(p, n, depth, "linear")
+    m.train()
+    masked, labels = s1.data_mask_device(tokens.to(DEV), 0.15, 0.9, 6, 6, rand_pick=pick.to(DEV),
+                                         rand_replace=rep.to(DEV))
+    omasked, olabels = MO.data_mask_tensor(tokens, 0.15, 0.9, 6, 6, rand_pick=pick, rand_replace=rep)
+    assert torch.equal(masked.cpu(), omasked) and torch.equal(labels.cpu(), olabels)       # index work: bit exact
+    out = m(masked)
+    loss = s1.masked_cross_entropy(out, labels, 6)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    leaves = {k: v.clone().requires_grad_() for k, v in p.items()
+              if v.dtype == torch.float32 and not k.endswith("projection_matrix")}
+    pp = dict(p)
+    pp.update(leaves)
+    ref = O.performer_lm_forward(omasked, pp, depth=depth, heads=10)
+    ref_loss = O.masked_ce_loss(ref, olabels, 6)
+    ref_loss.backward()
+    m_out = margin(out, ref.detach())
+    print(f"config 2 full size: logits margin {m_out:.3e} x rms, rel L2 {rell2(out, ref.detach()):.3e}, "
+          f"max/max {relmax(out, ref.detach()):.3e}; loss {loss.item():.6f} vs {ref_loss.item():.6f}")
+    assert m_out <= ATOL_RMS_ACT and rell2(out, ref.detach()) < TOL_L2
+    assert abs(loss.item() - ref_loss.item()) <= 2e-3 * abs(ref_loss.item())
+    worst_m, worst_l2 = ("", 0.0), ("", 0.0)
+    checked = 0
+    for k, par in m.named_parameters():
+        if k.startswith("pos_emb"):
+            assert par.grad is None
+            continue
+        assert par.grad is not None, k
+        g_ref = leaves[k].grad
+        mm, l2 = margin(par.grad, g_ref), rell2(par.grad, g_ref)
+        print(f"  grad {k:58s} margin {mm:.3e} x rms  rel L2 {l2:.3e}  |ref| {float(g_ref.norm()):.3e}")
+        if mm > worst_m[1]:
+            worst_m = (k, mm)
+        if l2 > worst_l2[1]:
+            worst_l2 = (k, l2)
+        checked += 1
+        assert mm <= ATOL_RMS_GRAD and l2 < TOL_GRAD, f"{k}: margin {mm:.3e}, rel L2 {l2:.3e}"
+    print(f"config 2 full size: {checked} parameter gradients; worst margin {worst_m}, worst rel L2 {worst_l2}")
+    assert checked == 1 + 14 * depth + 4

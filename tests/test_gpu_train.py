@@ -130,3 +130,103 @@ def test_batched_weight_refresh_matches_per_matrix_casts(mods):
         want = m.performer.net.layers[0][0].fn.fast_attention.projection_matrix
         got = stack._cache_of(m).store[("a", 0)][1]["omega_b"][:266].float()
         assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
+def test_two_optimizer_steps_vs_oracle_autograd_and_adam(mods):
+    """The S1 loop of s1_pretrain_rna.py:287-312 on the kernels (real PerformerLM, on-device masking with injected
+    draws, fused cross entropy, accumulation over 2 micro-steps, clip, Adam; eager and HIP-graph replay) against
+    the same loop written with the CPU oracle: oracle masking, oracle forward, torch autograd, torch.optim.Adam and
+    the same learning-rate schedule.  Compared: the four micro-step losses and accuracies, and after two optimizer
+    steps every weight.
+    Tolerances.  Losses: 2e-3 relative.  Accuracies: at most 2 predictions out of the ~45 masked positions per cell
+    may flip (a flip needs two logits closer than the bf16 noise).  Weights: Adam's first updates are
+    lr * g / (|g| + 1e-8) ~ lr * sign(g), so an element whose gradient is smaller than the bf16 noise of the
+    pipeline moves by +-lr in either direction; updates are therefore compared as vectors: cosine >= 0.95 and relative
+    L2 <= 0.35 per tensor (measured: printed), and no weight may differ by more than 2 optimizer steps' worth of lr."""
+    from oracle import masking_oracle as MO
+    from oracle import performer_oracle as O
+    ingest, s1, train = mods
+    n, depth, bsz, grad_acc, lr = 700, 2, 3, 2, 2e-3
+    p0 = O.make_params(51, depth=depth, max_seq_len=n)
+    toks = [O.standin_cells(60 + i, bsz, n) for i in range(4)]
+    gen = torch.Generator().manual_seed(9)
+    draws = [(torch.rand((bsz, n), generator=gen), torch.rand((bsz, n), generator=gen)) for _ in range(4)]
+
+    # ---- the oracle's loop
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    leaves = {k: v.clone().requires_grad_() for k, v in p0.items()
+              if v.dtype == torch.float32 and not k.endswith("projection_matrix")}
+    pp = dict(p0)
+    pp.update(leaves)
+    opt = torch.optim.Adam(list(leaves.values()), lr=lr)
+    sch = train.CosineAnnealingWarmupRestarts(opt, first_cycle_steps=15, cycle_mult=2, max_lr=lr, min_lr=1e-6,
+                                              warmup_steps=5, gamma=0.9)
+    sch.step(), sch.step()
+    ref_loss, ref_acc = [], []
+    for i in range(4):
+        masked, labels = MO.data_mask_tensor(toks[i], 0.15, 0.9, 6, 6, rand_pick=draws[i][0], rand_replace=draws[i][1])
+        logits = O.performer_lm_forward(masked, pp, depth=depth, heads=10)
+        loss = O.masked_ce_loss(logits, labels, 6) / grad_acc
+        loss.backward()
+        if (i + 1) % grad_acc == 0:
+            torch.nn.utils.clip_grad_norm_(list(leaves.values()), 100)
+            opt.step()
+            opt.zero_grad()
+        ref_loss.append(float(loss))
+        final = logits.detach().softmax(-1)[..., 1:-1].argmax(-1) + 1
+        counted = labels != 6
+        ref_acc.append(float(torch.true_divide((counted * (final == labels)).sum(-1), counted.sum(-1)).mean()))
+
+    for use_graph in (False, True):
+        m = _model(n, depth=depth)
+        m.load_state_dict(p0, strict=True)
+        m.fix_projection_matrices_()
+        m = m.to(DEV).train()
+        if use_graph:
+            # the recorded micro-step reads its draws from static buffers: refill them before every replay
+            pick_buf, rep_buf = draws[0][0].to(DEV).clone(), draws[0][1].to(DEV).clone()
+
+            def mask_fn(data, mp_, rp_, pad, mask):
+                return s1.data_mask_device(data, mp_, rp_, pad, mask, rand_pick=pick_buf, rand_replace=rep_buf)
+        else:
+            state = {"i": 0}
+
+            def mask_fn(data, mp_, rp_, pad, mask):
+                pick, rep = draws[state["i"]]
+                state["i"] += 1
+                return s1.data_mask_device(data, mp_, rp_, pad, mask, rand_pick=pick.to(DEV), rand_replace=rep.to(DEV))
+
+        tr = train.S1Trainer(m, learning_rate=lr, grad_acc=grad_acc, use_graph=use_graph, mask_fn=mask_fn)
+        tr.scheduler.step(), tr.scheduler.step()
+        if use_graph:
+            tr.prepare(toks[0].to(DEV))
+        got_loss, got_acc = [], []
+        for i in range(4):
+            if use_graph:
+                pick_buf.copy_(draws[i][0]), rep_buf.copy_(draws[i][1])
+            l_, a_ = tr.micro_step(toks[i].to(DEV))
+            got_loss.append(float(l_)), got_acc.append(float(a_))
+        m.raise_on_bad_token()
+        print(f"graph={use_graph}: losses {got_loss} vs oracle {ref_loss}; accuracies {got_acc} vs {ref_acc}")
+        for a, b_ in zip(got_loss, ref_loss):
+            assert abs(a - b_) <= 2e-3 * abs(b_)
+        for a, b_ in zip(got_acc, ref_acc):
+            assert abs(a - b_) <= 2.0 / 40
+        lr_now = opt.param_groups[0]["lr"]
+        assert abs(tr.optimizer.param_groups[0]["lr"] - lr_now) < 1e-12
+        sd = m.state_dict()
+        worst_cos, worst_l2 = ("", 1.0), ("", 0.0)
+        for k, leaf in leaves.items():
+            upd_ref = (leaf.detach() - p0[k]).double().flatten()
+            upd = (sd[k].cpu() - p0[k]).double().flatten()
+            assert float((upd - upd_ref).abs().max()) <= 2 * 2 * lr_now * 1.01, k
+            if upd_ref.numel() < 1000:
+                continue                                     # tiny tensors: a handful of flips dominates the measures
+            cos = float(upd @ upd_ref / (upd.norm() * upd_ref.norm()))
+            l2 = float((upd - upd_ref).norm() / upd_ref.norm())
+            if cos < worst_cos[1]:
+                worst_cos = (k, cos)
+            if l2 > worst_l2[1]:
+                worst_l2 = (k, l2)
+            assert cos >= 0.95 and l2 <= 0.35, f"{k}: update cosine {cos:.4f}, rel L2 {l2:.3f}"
+        print(f"graph={use_graph}: weight updates vs oracle Adam: worst cosine {worst_cos}, worst rel L2 {worst_l2}")
