@@ -138,11 +138,11 @@ def test_two_optimizer_steps_vs_oracle_autograd_and_adam(mods):
     the same loop written with the CPU oracle: oracle masking, oracle forward, torch autograd, torch.optim.Adam and
     the same learning-rate schedule.  Compared: the four micro-step losses and accuracies, and after two optimizer
     steps every weight.
-    Tolerances.  Losses: 2e-3 relative.  Accuracies: at most 2 predictions out of the ~45 masked positions per cell
-    may flip (a flip needs two logits closer than the bf16 noise).  Weights: Adam's first updates are
+    Tolerances.  Losses: 1e-3 relative.  Accuracies: at most 1 prediction out of the ~45 masked positions per cell
+    may flip (a flip needs two logits closer than the bf16 noise; measured: none flips).  Weights: Adam's first updates are
     lr * g / (|g| + 1e-8) ~ lr * sign(g), so an element whose gradient is smaller than the bf16 noise of the
-    pipeline moves by +-lr in either direction; updates are therefore compared as vectors: cosine >= 0.95 and relative
-    L2 <= 0.35 per tensor (measured: printed), and no weight may differ by more than 2 optimizer steps' worth of lr."""
+    pipeline moves by +-lr in either direction; updates are therefore compared as vectors: cosine >= 0.99 and relative
+    L2 <= 0.13 per tensor (measured on MI355X: 0.998 and 0.062 at worst), and no weight may differ by more than 2 optimizer steps' worth of lr."""
     from oracle import masking_oracle as MO
     from oracle import performer_oracle as O
     ingest, s1, train = mods
@@ -209,9 +209,9 @@ def test_two_optimizer_steps_vs_oracle_autograd_and_adam(mods):
         m.raise_on_bad_token()
         print(f"graph={use_graph}: losses {got_loss} vs oracle {ref_loss}; accuracies {got_acc} vs {ref_acc}")
         for a, b_ in zip(got_loss, ref_loss):
-            assert abs(a - b_) <= 2e-3 * abs(b_)
+            assert abs(a - b_) <= 1e-3 * abs(b_)                  # measured: 4.4e-4 at worst
         for a, b_ in zip(got_acc, ref_acc):
-            assert abs(a - b_) <= 2.0 / 40
+            assert abs(a - b_) <= 1.0 / 40
         lr_now = opt.param_groups[0]["lr"]
         assert abs(tr.optimizer.param_groups[0]["lr"] - lr_now) < 1e-12
         sd = m.state_dict()
@@ -228,5 +228,5 @@ def test_two_optimizer_steps_vs_oracle_autograd_and_adam(mods):
                 worst_cos = (k, cos)
             if l2 > worst_l2[1]:
                 worst_l2 = (k, l2)
-            assert cos >= 0.95 and l2 <= 0.35, f"{k}: update cosine {cos:.4f}, rel L2 {l2:.3f}"
+            assert cos >= 0.99 and l2 <= 0.13, f"{k}: update cosine {cos:.4f}, rel L2 {l2:.3f}"
         print(f"graph={use_graph}: weight updates vs oracle Adam: worst cosine {worst_cos}, worst rel L2 {worst_l2}")
