@@ -76,6 +76,18 @@ int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* 
                const float* dres, int64_t T, int D, float* dx, void* dx_bf16, float* ws, float* dgamma,
                float* dbeta, float* dres_colsum, int accumulate, void* stream);
 
+/* The same LayerNorm backward for callers that cannot allocate or carry a workspace (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The column
+ * partials live in an array built into the library's code object (3 MiB per GPU, kept until the process ends)
+ * instead of `ws`; nothing is allocated or freed, on the device or through any library.  Limits: D <= 256 and
+ * D % 4 == 0 as above, any T (the partial count is capped at 1024 workgroups); a size beyond the array is rejected
+ * with SCM_EINVAL.  The first call on a device looks the array's address up (make that call outside a graph
+ * capture).  All calls on one GPU share the array: calls that overlap on one GPU (different streams) race; calls
+ * on one stream are ordered and safe.  Results are bit-identical to scm_ln_bwd's. */
+int scm_ln_bwd_noalloc(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* dres, int64_t T, int D, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                       float* dres_colsum, int accumulate, void* stream);
+
 /* ---- nn.Linear products: performer_pytorch.py:374 (to_q/k/v), :402 (to_out), :323,330 (FeedForward) ---- */
 /* Y[M,N] = A[M,K] * W[N,K]^T with a fused epilogue; A is bf16 or (a_f32) f32, W bf16, K % 8 == 0, N % 8 == 0,
  * leading dimensions multiples of 8 elements and 16-byte aligned bases.

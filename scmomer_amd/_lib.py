@@ -38,6 +38,7 @@ SIGNATURES = {
     "scm_ln_fwd": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp]),
     "scm_ln_bwd_ws_floats": (i64, [i64, i32]),
     "scm_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "scm_ln_bwd_noalloc": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp]),
     "scm_gemm_nt": (i32, [i32, i32, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]),
     "scm_wgrad_ws_floats": (i64, [i32, i32]),
     "scm_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, i32, i32, vp]),

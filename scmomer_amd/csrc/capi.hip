@@ -161,6 +161,19 @@ int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* 
   return 0;
 }
 
+int scm_ln_bwd_noalloc(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* dres, int64_t T, int D, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                       float* dres_colsum, int accumulate, void* stream) {
+  SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0, "scm_ln_bwd_noalloc: need T > 0, 0 < D <= 256, D %% 4 == 0");
+  SCM_REQ((int64_t)ln_bwd_blocks(T) * 3 * D <= LN_STATIC_SCRATCH_FLOATS,
+          "scm_ln_bwd_noalloc: T=%lld, D=%d need more than the built-in scratch of %d floats", (long long)T, D,
+          LN_STATIC_SCRATCH_FLOATS);
+  float* ws = nullptr;
+  SCM_HIP(ln_bwd_static_scratch(&ws), "scm_ln_bwd_noalloc(scratch address)");
+  return scm_ln_bwd(dy, x, mean, rstd, gamma, dres, T, D, dx, dx_bf16, ws, dgamma, dbeta, dres_colsum, accumulate,
+                    stream);
+}
+
 int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
                 void* out0, int64_t ldo0, void* out1, int64_t ldo1, const float* bias, const float* resid, int64_t ldr,
                 const void* pre, int64_t ldp, void* stream) {

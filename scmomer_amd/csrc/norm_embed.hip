@@ -8,6 +8,7 @@
 //                          rna_encoder.py:5-16 1x200 conv + ReLU) and backward
 //  colsum_reduce         : sums per-workgroup partial rows into the f32 gradient
 #include "scm_launch.hpp"
+#include <mutex>
 
 namespace scm {
 
@@ -382,6 +383,31 @@ hipError_t ln_bwd(const float* dy, const float* x, const float* mean, const floa
                      (bf16*)dx_b, partial);
   return hipGetLastError();
 }
+// ---------------------------------------------------------------- LayerNorm backward without a caller workspace
+// The per-workgroup column partials of ln_bwd (at most 1024 workgroups x 3 x D floats, D <= 256) in a fixed array of
+// the code object instead of a caller buffer: 3 MiB per GPU, held for the life of the process.  On the host the
+// array's name is only a handle: its device address differs per GPU and is looked up once per device.
+static __device__ __align__(256) float ln_bwd_scratch[LN_STATIC_SCRATCH_FLOATS];
+
+hipError_t ln_bwd_static_scratch(float** out) {
+  static float* addr[64] = {};                // per device; written once, under the mutex
+  static std::mutex mu;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!addr[dev]) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(ln_bwd_scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    addr[dev] = p;
+  }
+  *out = addr[dev];
+  return hipSuccess;
+}
+
 hipError_t head_fwd(const float* x, const float* g, const float* b, const float* W, const float* bias, long T, int D,
                     int C, int relu, float* enc, float* out, float* mean, float* rstd, hipStream_t s) {
   Traced tr(K_HEAD_FWD, 0, s);

@@ -109,6 +109,8 @@ hipError_t embed_bwd(const int64_t* tok, const float* dx, long T, int D, int V, 
 hipError_t ln_fwd(const float* x, const float* g, const float* b, long T, int D, void* y, float* mean, float* rstd,
                   hipStream_t s);
 int ln_bwd_blocks(long T);
+constexpr int LN_STATIC_SCRATCH_FLOATS = 1024 * 3 * 256;   // ln_bwd_blocks(T) <= 1024, D <= 256
+hipError_t ln_bwd_static_scratch(float** device_ptr);       // this device's address of the built-in scratch array
 hipError_t ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                   const float* dres, long T, int D, float* dx, void* dx_b, float* partial, hipStream_t s);
 hipError_t head_fwd(const float* x, const float* g, const float* b, const float* W, const float* bias, long T, int D,
