@@ -39,10 +39,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-all", action="store_true", help="time every kernel (per-kernel table to stderr)")
     ap.add_argument("--eager", action="store_true", help="drive every launch from Python instead of a HIP graph")
-    ap.add_argument("--mode", choices=("train", "extract", "finetune"), default="train",
+    ap.add_argument("--cells", type=int, default=3072, help="extract mode: cells per GPU in the synthetic cell list")
+    ap.add_argument("--mode", choices=("train", "extract", "finetune", "s3"), default="train",
                     help="train: the S1 micro-step (the headline metric); extract: forward-only cell-embedding "
                          "extraction (scMomer.get_cell_embedding); finetune: the cell-type fine-tune step "
-                         "(frozen encoder except its second-to-last layer, norm and head); secondary figures")
+                         "(frozen encoder except its second-to-last layer, norm and head); s3: the distillation step with the "
+                         "frozen encoder in train mode; secondary figures")
     return ap.parse_args()
 
 
@@ -58,33 +60,63 @@ def build_model(device):
     return model.to(device)
 
 
-def cpu_baseline():
-    """CPU oracle, B=1 forward+backward with the CE loss at the full 16,906 tokens, three timed passes (about 10 s of
-    CPU work), after a small warm-up call that pages the math libraries in."""
+def _cpu_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
+    return model, share
+
+
+def cpu_baseline(mode="train"):
+    """The CPU oracle (a port of the reference path, pinned against the reference's own outputs) on this host, fp32,
+    with every core this process may use: torch's own thread count, which follows OMP_NUM_THREADS / the affinity
+    mask (on a shared GPU box that is this GPU's CPU share, not the machine's core count: oversubscribing a cgroup
+    share slows the oracle down).  Timed: config 1 (one cell, forward, eval: 1 warm-up + 3 passes) and the metric's
+    own workload (3 cells, forward + CE + backward: 1 pass, about 24 GB of host memory), about 20 s in all.
+    `value` is the rate of the workload the GPU line reports (train: B=3 forward+backward; extract: B=1 forward)."""
     from oracle import performer_oracle as O
     import numpy as np
-    threads = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(threads)
+    cpu_model, share = _cpu_info()
+    threads = torch.get_num_threads()
     p = O.make_params(2024, depth=6, max_seq_len=N_GENES)
+    cells = O.synthetic_cells(2024, BATCH, N_GENES)
+    tokens = torch.from_numpy(np.minimum(cells, 5).astype(np.int64))
+    with torch.no_grad():
+        O.performer_lm_forward(tokens[:1, :2048], p, depth=6, heads=10)          # pages the math libraries in
+        O.performer_lm_forward(tokens[:1], p, depth=6, heads=10)                 # warm-up at full length
+        t0 = time.perf_counter()
+        for _ in range(3):
+            O.performer_lm_forward(tokens[:1], p, depth=6, heads=10)
+        fwd = (time.perf_counter() - t0) / 3
+    out = {"unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": cpu_model, "cpus_available": share,
+           "cpus_in_machine": os.cpu_count(), "forward_b1_cells_per_s": 1.0 / fwd, "forward_b1_seconds": fwd}
+    if mode == "extract":
+        out.update(value=1.0 / fwd, sample="config 1: 1 cell (B=1), encoder forward at 16906 tokens, eval, fp32 "
+                                           f"torch-CPU oracle, mean of 3 timed passes ({fwd:.2f} s each)")
+        return out
     leaves = {k: v.clone().requires_grad_() for k, v in p.items()
               if v.dtype == torch.float32 and not k.endswith("projection_matrix")}
     pp = dict(p)
     pp.update(leaves)
-    cells = O.synthetic_cells(2024, 1, N_GENES)
-    tokens = torch.from_numpy(np.minimum(cells, 5).astype(np.int64))
     labels = tokens.clone()
     labels[torch.rand(tokens.shape) > 0.15] = 6
-    small = tokens[:, :2048]
-    O.masked_ce_loss(O.performer_lm_forward(small, pp, depth=6, heads=10), labels[:, :2048], 6).backward()
-    passes = 3
     t0 = time.perf_counter()
-    for _ in range(passes):
-        loss = O.masked_ce_loss(O.performer_lm_forward(tokens, pp, depth=6, heads=10), labels, 6)
-        loss.backward()
-    dt = (time.perf_counter() - t0) / passes
-    return {"value": 1.0 / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"1 cell (B=1), forward+backward+CE at 16906 tokens, fp32 torch-CPU oracle, mean of {passes} "
-                      f"timed passes ({dt:.1f} s each)"}
+    loss = O.masked_ce_loss(O.performer_lm_forward(tokens, pp, depth=6, heads=10), labels, 6)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    out.update(value=BATCH / dt, fwd_bwd_b3_seconds=dt,
+               sample=f"config 2's workload: 3 cells (B=3), forward + CE + backward at 16906 tokens, fp32 torch-CPU "
+                      f"oracle, 1 timed pass ({dt:.1f} s); config 1 (B=1 forward, eval): {fwd:.2f} s per cell")
+    return out
 
 
 # trace id -> kernel symbol as rocprofv3 lists it (for the counter-derived traffic of the dominant kernel)
@@ -96,7 +128,7 @@ TRACE_SYMBOL = {"favor_apply_fwd": "favor_apply_kernel<0>", "favor_apply_bwd_q":
                 "gemm_skinny/gelu_dual": "gemm_skinny_kernel<false, 2>", "gemm_skinny/dgelu": "gemm_skinny_kernel<false, 3>"}
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, pattern="r*_pmc_fetch_write_summary.txt"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (profiles/rNN_pmc_fetch_write_
     summary.txt: separate FETCH_SIZE and WRITE_SIZE passes of this same bench, mean per dispatch, in KB).  On gfx950
     FETCH_SIZE counts wide coalesced reads at half their bytes, so it is doubled; WRITE_SIZE is exact.  None when no
@@ -104,7 +136,7 @@ def measured_traffic(kernel):
     import glob
     import re
     sym = TRACE_SYMBOL.get(kernel)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not sym or not files:
         return None, None
     lines = open(files[-1]).read().splitlines()
@@ -119,15 +151,21 @@ def measured_traffic(kernel):
 
 
 def run_extract(args, world, rank, device):
-    """Forward-only extraction (scmomer.py:96-113): binning, frozen Performer encoder with the per-gene conv head,
-    projection to 128, normalisation, student encoder, to_out.  Cells are sharded contiguously over the ranks; there
-    is no collective.  One step = one batch of args.batch cells (24 by default: one full round of workgroups)."""
+    """Config 4: batched embedding extraction (evaluate_embedding.py:173-178: scMomer.get_cell_embedding over a cell
+    list, scmomer.py:96-113) sharded over the ranks.  The synthetic cell list has --cells cells PER GPU (weak
+    scaling; 1M cells over 8 GPUs is 125,000 each); rank r owns one contiguous shard, walks it in batches of
+    --batch cells (24 by default: one full round of attention workgroups) and keeps its [cells, 128] block on the
+    device; the only collective is the final gather.  The expression rows come from a pool of distinct synthetic
+    cells resident in HBM (cell i = pool row i mod pool size): a 1M-cell float matrix is 68 GB and would be
+    streamed from host memory or disk in production, which is not what this line measures.  One step = one batch;
+    the timed region is the whole job including the gather."""
     import types
     import torch.distributed as dist
     import scmomer_amd as S
     from scmomer_amd import dist as sdist
-    from scmomer_amd import ops
+    from scmomer_amd import extract, ops
     batch = args.batch if args.batch != BATCH else 24
+    n_cells = world * args.cells
     torch.manual_seed(2024)
     cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
     model = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(N_GENES, 128))
@@ -137,49 +175,123 @@ def run_extract(args, world, rank, device):
     model = model.to(device).eval()
     for p in model.parameters():
         p.requires_grad = False
-    gen = torch.Generator().manual_seed(100 + rank)
-    cells = [((torch.rand((batch, N_GENES), generator=gen) < 0.15) *
-              torch.distributions.Gamma(2.0, 1 / 1.2).sample((batch, N_GENES))).float().to(device) for _ in range(2)]
+    pool_n = 8 * batch
+    gen = torch.Generator().manual_seed(100)
+    pool = ((torch.rand((pool_n, N_GENES), generator=gen) < 0.15) *
+            torch.distributions.Gamma(2.0, 1 / 1.2).sample((pool_n, N_GENES))).float().to(device)
+
+    def source(lo, hi):
+        return pool[torch.arange(lo, hi, device=device) % pool_n]
+
+    shard = sdist.contiguous_shard(n_cells, rank, world)
+    steps = (len(shard) + batch - 1) // batch
+    extract.extract_embeddings(model, source, min(n_cells, world * batch * max(args.warmup, 1)), batch, rank=rank,
+                               world=world, device=device)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    local = extract.extract_embeddings(model, source, n_cells, batch, rank=rank, world=world, device=device)
+    full = extract.gather_embeddings(local, n_cells)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = sdist.max_over_ranks(time.perf_counter() - t0, device)
+    assert tuple(full.shape) == (n_cells, 128)
+    ops.trace_collect()
+    ops.trace_enable("all")
     with torch.no_grad():
-        for i in range(max(args.warmup, 1)):
-            out = model.get_cell_embedding(cells[i % 2])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = model.get_cell_embedding(cells[i % 2])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = sdist.max_over_ranks(time.perf_counter() - t0, device)
-        ops.trace_collect()
-        ops.trace_enable("all")
-        model.get_cell_embedding(cells[0])
-        torch.cuda.synchronize()
-        ops.trace_enable(None)
-        trace = ops.trace_collect()
+        model.get_cell_embedding(source(0, batch))
+    torch.cuda.synchronize()
+    ops.trace_enable(None)
+    trace = ops.trace_collect()
     if rank == 0:
-        value = world * batch * args.steps / dt
+        value = n_cells / dt
         dominant = max(trace, key=lambda k: trace[k][0])
         ms, fl, cnt, by = trace[dominant]
         gbs = by / (ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(dominant, "r*_pmc_fetch_write_extract_summary.txt")
         kernels = {k: {"ms_per_step": round(m_, 4), "launches_per_step": c_, "gbs": round(b_ / (m_ * 1e-3) / 1e9, 1)}
                    for k, (m_, f_, c_, b_) in sorted(trace.items(), key=lambda kv: -kv[1][0])}
+        base = cpu_baseline("extract") if world == 1 and not args.no_cpu_baseline else None
         print(json.dumps({
             "metric": "cells/sec, Performer RNA encoder forward (cell-embedding extraction, 16.9k genes)",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "scMomer.get_cell_embedding over a sharded cell list (RNA-only configuration, "
+                                   "frozen encoder), final gather of [cells, 128] included",
+                       "cells_total": n_cells, "cells_per_gpu": args.cells, "cells_per_batch": batch,
+                       "gene_tokens": N_GENES, "depth": 6, "dim": 200, "heads": 10, "nb_features": 266,
+                       "parallelism": f"dp{world}"},
+            "embedding_norm": float(full.float().norm(dim=-1).mean().item()),
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": ms / cnt, "algorithmic_bytes_per_launch": by / cnt,
+                         "whole_step_frac_of_mfma_peak": value / world * 307.52e9 / 1e12 / PEAK_BF16_TFLOPS},
+            "cpu_baseline": base, "kernels": kernels}))
+
+
+def run_s3(args, world, rank, device):
+    """Config 5: the S3 distillation step (s3_pretrain_missing.py:286-316): scMomer(mode='one', reconstruct=True)
+    in train() mode with the Performer frozen (forward only, no tape), trainable student encoder, to_out and linear
+    decoders; BCE + MSE + distillation loss against precomputed teacher embeddings; backward through the tail,
+    gradient average over the ranks, clip 1e4, Adam.  One step = one batch of 3 cells (the script's default)."""
+    import types
+    import torch.distributed as dist
+    import scmomer_amd as S
+    from scmomer_amd import dist as sdist
+    from scmomer_amd import s3
+    batch, n_peaks = args.batch, 20000
+    torch.manual_seed(2024)
+    cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+    model = S.scMomer(cfg, atac_config=None, rna_decoder=s3.ReconstructNet(N_GENES, 128),
+                      atac_decoder=s3.ReconstructNet(n_peaks, 128), encoder=S.StudentEncoder(N_GENES, 128))
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        model.rna_model.model.pos_emb.emb.weight[:N_GENES] = torch.randn((N_GENES, 200), generator=gen, dtype=torch.float64)
+    s3.freeze_for_distillation(model)
+    model.rna_model.model.fix_projection_matrices_()
+    model = model.to(device).train()
+    stepper = s3.S3Step(model, lr=1e-4, grad_acc=args.grad_acc, pos_weight=1.0, distill_weight=1.0)
+    gen = torch.Generator().manual_seed(100 + rank)
+    data = []
+    for _ in range(2):
+        rna = ((torch.rand((batch, N_GENES), generator=gen) < 0.15) *
+               torch.distributions.Gamma(2.0, 1 / 1.2).sample((batch, N_GENES))).float().to(device)
+        atac = (torch.rand((batch, n_peaks), generator=gen) < 0.05).float().to(device)
+        latent = torch.randn((batch, 128), generator=gen).to(device)
+        data.append((rna, atac, latent))
+    for i in range(max(args.warmup, 1)):
+        losses = stepper.micro_step(*data[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = stepper.micro_step(*data[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = sdist.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        value = world * batch * args.steps / dt
+        print(json.dumps({
+            "metric": "cells/sec, S3 distillation step (frozen Performer forward + trainable tail fwd/bwd, 16.9k genes)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "scMomer.get_cell_embedding, RNA-only configuration, frozen encoder",
-                       "cells_per_gpu_per_step": batch, "gene_tokens": N_GENES, "depth": 6, "dim": 200, "heads": 10,
-                       "nb_features": 266, "parallelism": f"dp{world}"},
-            "embedding_norm": float(out.float().norm(dim=-1).mean().item()),
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms / cnt,
-                         "whole_step_frac_of_mfma_peak": value / world * 307.52e9 / 1e12 / PEAK_BF16_TFLOPS},
-            "cpu_baseline": None, "kernels": kernels}))
+            "config": {"workload": "scMomer.forward(mode='one', reconstruct=True), train mode, frozen encoder; BCE + "
+                                   "MSE + distillation loss; backward; clip + Adam every grad_acc steps",
+                       "cells_per_gpu_per_step": batch, "gene_tokens": N_GENES, "atac_peaks": n_peaks, "depth": 6,
+                       "dim": 200, "heads": 10, "nb_features": 266, "grad_acc": args.grad_acc,
+                       "parallelism": f"dp{world}", "launch": "eager"},
+            "final_losses": {k: float(v.item()) for k, v in losses.items()},
+            "redraw_counter": int(model.rna_model.model.performer.calls_since_last_redraw),
+            "roofline": {"whole_step_frac_of_mfma_peak": value / world * 307.52e9 / 1e12 / PEAK_BF16_TFLOPS},
+            "cpu_baseline": None}))
 
 
 def run_finetune(args, world, rank, device):
@@ -315,8 +427,8 @@ def main():
                                 world_size=world, rank=rank)
 
     _say("process group up")
-    if args.mode in ("extract", "finetune"):
-        (run_extract if args.mode == "extract" else run_finetune)(args, world, rank, device)
+    if args.mode in ("extract", "finetune", "s3"):
+        {"extract": run_extract, "finetune": run_finetune, "s3": run_s3}[args.mode](args, world, rank, device)
         if world > 1:
             dist.destroy_process_group()
         return

@@ -167,3 +167,27 @@ def test_redrawn_projections_stay_identical_across_ranks(tmp_path):
     torch.manual_seed(200)
     want = P.gaussian_orthogonal_random_matrix(266, 64)
     assert torch.equal(r1["after"][0], want)
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from scmomer_amd import extract
+        n_cells = 7                                     # shards of 4 and 3 cells: the blocks are padded for the gather
+        shard = sdist.contiguous_shard(n_cells, rank, world)
+        local = torch.arange(shard.start, shard.stop, dtype=torch.float32)[:, None] * torch.ones(1, 5) + 0.5 * rank
+        full = extract.gather_embeddings(local, n_cells)
+        torch.save(full, os.path.join(out_dir, f"full{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_extraction_gather_keeps_cell_order_with_uneven_shards(tmp_path):
+    world = 2
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    f0 = torch.load(os.path.join(tmp_path, "full0.pt"))
+    f1 = torch.load(os.path.join(tmp_path, "full1.pt"))
+    assert torch.equal(f0, f1) and f0.shape == (7, 5)
+    want = torch.arange(7, dtype=torch.float32) + torch.tensor([0, 0, 0, 0, 0.5, 0.5, 0.5])
+    assert torch.equal(f0[:, 0], want) and torch.equal(f0[:, 4], want)

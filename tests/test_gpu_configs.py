@@ -1,0 +1,140 @@
+"""GPU checks of the two secondary configurations: sharded embedding extraction (the loop of
+evaluate_embedding.py:173-178 cut into per-rank shards) and the S3 distillation step
+(s3_pretrain_missing.py:286-316: frozen Performer in train mode, trainable tail)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import performer_oracle as O
+from parity_util import margin, rell2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N = 16906
+
+
+@pytest.fixture(scope="module")
+def S():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import scmomer_amd
+    return scmomer_amd
+
+
+def _scmomer(S, p, **kw):
+    cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+    m = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(N, 128, dropout=0.0), **kw)
+    m.load_state_dict(p, strict=False)
+    return m.to(DEV)
+
+
+def test_sharded_extraction_equals_one_pass(S):
+    """Two contiguous shards walked independently and concatenated == one rank walking the whole list, bit for bit,
+    when the shard length is a multiple of the batch size (same cells share a batch: same key stabiliser);
+    otherwise the batches differ in composition and the results agree within the bf16 tolerance."""
+    from scmomer_amd import extract
+    p = O.make_scmomer_params(5)
+    m = _scmomer(S, p).eval()
+    for q in m.parameters():
+        q.requires_grad = False
+    cells = torch.from_numpy(O.synthetic_cells(9, 50, N))           # host matrix: batches are copied over one by one
+    one = extract.extract_embeddings(m, cells, 48, 12, device=DEV)
+    parts = [extract.extract_embeddings(m, cells, 48, 12, rank=r, world=2, device=DEV) for r in range(2)]
+    assert one.shape == (48, 128) and parts[0].shape == (24, 128)
+    assert torch.equal(torch.cat(parts, 0), one)
+    assert torch.equal(extract.gather_embeddings(one, 48), one)     # no process group: the local block is the result
+    # a cell source given as a function of the index range, shards of 25 cells in batches of 12 (12 + 12 + 1)
+    dev_cells = cells.to(DEV)
+    uneven = [extract.extract_embeddings(m, lambda lo, hi: dev_cells[lo:hi], 50, 12, rank=r, world=2, device=DEV)
+              for r in range(2)]
+    assert [u.shape[0] for u in uneven] == [25, 25]
+    got = torch.cat(uneven, 0)
+    ref = extract.extract_embeddings(m, dev_cells, 50, 12, device=DEV)
+    assert margin(got, ref) <= 2e-2 and rell2(got, ref) < 4e-3
+    assert torch.equal(got[:24], ref[:24])                           # the first two batches hold the same cells
+    # against the CPU oracle: the first batch of the list
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        want = O.scmomer_cell_embedding(cells[:12], p)
+    print(f"extraction batch vs oracle: margin {margin(one[:12], want):.3e}, rel L2 {rell2(one[:12], want):.3e}")
+    assert margin(one[:12], want) <= 4e-2 and rell2(one[:12], want) < 4e-3
+    empty = extract.extract_embeddings(m, cells, 1, 12, rank=1, world=2, device=DEV)
+    assert empty.shape == (0, 128)
+
+
+def test_s3_distillation_step_vs_oracle(S):
+    """model.train(); Performer frozen; mode='one', reconstruct=True with linear decoders; BCE + MSE + distillation
+    loss and its backward against autograd over the CPU oracle.  The Performer gets no gradient, its redraw counter
+    ticks once per forward (the reference ticks it in train mode even when frozen), the optimizer step moves only
+    the trainable tail."""
+    from scmomer_amd import s3
+    n_peaks, bsz = 3000, 3
+    p = O.make_scmomer_params(6)
+    rng = np.random.default_rng(60)
+    t = lambda *s_, sc=0.05: torch.from_numpy((rng.standard_normal(s_) * sc).astype(np.float32))
+    dec = {"RNA.output_mean.0.weight": t(N, 128), "RNA.output_mean.0.bias": t(N),
+           "ATAC.output_mean.0.weight": t(n_peaks, 128), "ATAC.output_mean.0.bias": t(n_peaks)}
+    m = _scmomer(S, {**p, **dec}, rna_decoder=s3.ReconstructNet(N, 128), atac_decoder=s3.ReconstructNet(n_peaks, 128))
+    total, trainable = s3.freeze_for_distillation(m)
+    assert trainable == sum(v.numel() for k, v in {**p, **dec}.items()
+                            if k.startswith(("encoder.", "to_out.", "RNA.", "ATAC.")))
+    m.train()
+    perf = m.rna_model.model.performer
+    perf.fix_projection_matrices_()
+    rna = torch.from_numpy(O.synthetic_cells(61, bsz, N))
+    atac_raw = torch.from_numpy((rng.random((bsz, n_peaks)) < 0.05).astype(np.float32) * 2.0)
+    latent = t(bsz, 128, sc=1.0)
+    step = s3.S3Step(m, lr=1e-3, grad_acc=1, pos_weight=2.0, distill_weight=0.5)
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    losses = s3.distillation_losses(m, rna.to(DEV), atac_raw.to(DEV), latent.to(DEV), step.pos_weight, 0.5)
+    losses["total"].backward()
+    assert int(perf.calls_since_last_redraw) == 1
+
+    # ---- oracle: the same step in f32 on the CPU
+    names = [k for k in {**p, **dec} if k.startswith(("encoder.", "to_out.", "RNA.", "ATAC."))]
+    leaves = {k: {**p, **dec}[k].clone().requires_grad_() for k in names}
+    pp = {**p, **dec, **leaves}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    tokens = torch.round(rna).long().clamp(min=0, max=5)
+    lm = {k[len("rna_model.model."):]: v for k, v in pp.items() if k.startswith("rna_model.model.")}
+    with torch.no_grad():
+        per_gene = O.performer_lm_forward(tokens, lm, depth=6, heads=10, head="conv")
+        feat = per_gene @ pp["rna_projection.weight"].t()
+        feat = feat / feat.norm(dim=-1, keepdim=True)
+        feat = O.layer_norm(feat, pp["rna_ln.weight"], pp["rna_ln.bias"])
+    h = rna @ pp["encoder.encoder.0.weight"].t() + pp["encoder.encoder.0.bias"]
+    h = O.gelu_erf(O.layer_norm(h, pp["encoder.encoder.1.weight"], pp["encoder.encoder.1.bias"]))
+    student = h @ pp["encoder.encoder.4.weight"].t() + pp["encoder.encoder.4.bias"]
+    out = torch.cat([student, feat], 1) @ pp["to_out.weight"].t() + pp["to_out.bias"]
+    r_atac = out @ pp["ATAC.output_mean.0.weight"].t() + pp["ATAC.output_mean.0.bias"]
+    r_rna = out @ pp["RNA.output_mean.0.weight"].t() + pp["RNA.output_mean.0.bias"]
+    l_atac = torch.nn.functional.binary_cross_entropy_with_logits(r_atac, (atac_raw > 0).float(),
+                                                                  pos_weight=torch.tensor([2.0]))
+    l_rna = torch.nn.functional.mse_loss(r_rna, rna)
+    l_dis = torch.nn.functional.mse_loss(student, latent)
+    (l_atac + l_rna + 0.5 * l_dis).backward()
+    for k, want in (("atac", l_atac), ("rna", l_rna), ("distill", l_dis)):
+        print(f"S3 loss {k}: {float(losses[k]):.6f} vs oracle {float(want):.6f}")
+        assert abs(float(losses[k]) - float(want)) <= 1e-3 * abs(float(want))
+    got = dict(m.named_parameters())
+    worst = 0.0
+    for k in names:
+        e = rell2(got[k].grad, leaves[k].grad)
+        worst = max(worst, e)
+        assert e < 1e-2, f"{k}: grad rel L2 {e:.3e}"
+    print(f"S3: {len(names)} tail gradients, worst rel L2 {worst:.3e}")
+    for k, q in got.items():
+        if k.startswith(("rna_model.", "rna_projection.", "rna_ln.", "atac_ln.")):
+            assert q.grad is None and not q.requires_grad, k
+
+    # ---- the optimizer step of the driver: only the tail moves; the counter keeps ticking
+    m.zero_grad(set_to_none=True)
+    out_losses = step.micro_step(rna.to(DEV), atac_raw.to(DEV), latent.to(DEV))
+    assert abs(float(out_losses["total"]) - float(losses["total"])) <= 1e-6 * abs(float(losses["total"]))
+    assert int(perf.calls_since_last_redraw) == 2
+    after = dict(m.named_parameters())
+    for k, v in before.items():
+        moved = not torch.equal(after[k].detach(), v)
+        assert moved == k.startswith(("encoder.", "to_out.", "RNA.", "ATAC.")), k
