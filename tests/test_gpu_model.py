@@ -362,4 +362,4 @@ def test_full_size_config2_forward_backward_vs_oracle():
         checked += 1
         assert mm <= ATOL_RMS_GRAD and l2 < TOL_GRAD, f"{k}: margin {mm:.3e}, rel L2 {l2:.3e}"
     print(f"config 2 full size: {checked} parameter gradients; worst margin {worst_m}, worst rel L2 {worst_l2}")
-    assert checked == 1 + 14 * depth + 4
+    assert checked == 1 + 13 * depth + 4      # token_emb, 13 tensors per layer, final norm and head
