@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscmomer_hip.so")
+# SCMOMER_HIP_LIB: another build of the same library (diagnostic builds with in-kernel stamps, experiments)
+LIB_PATH = os.environ.get("SCMOMER_HIP_LIB") or os.path.join(_HERE, "libscmomer_hip.so")
 
 
 class View4(C.Structure):
