@@ -805,16 +805,26 @@ __global__ void cast_weight_kernel(const float* __restrict__ src, int R, int C, 
   if (dstT) dstT[(long)c * R + r] = v;
 }
 
+// "Chain order" of the k index of a weight that is the SECOND operand of a chained product (ffn_chain.hip): inside
+// every block of 64, unit u = 32 s + 16 e + 8 h + 4 t + i sits at position 32 t + 16 s + 8 h + 4 e + i, the order in
+// which the first product's accumulator registers (tile t, registers 8s..8s+7, lane-half h) come out as the bf16
+// B fragment of k-step 2t + s.
+__host__ __device__ inline int chain_pos(int u) {
+  const int b = u & ~63, v = u & 63;
+  return b | (((v >> 2) & 1) << 5) | (((v >> 5) & 1) << 4) | (((v >> 3) & 1) << 3) | (((v >> 4) & 1) << 2) | (v & 3);
+}
+
 // The same for a whole table of weights in one launch (grid.y = entry): an entry casts src [R,C] into
 // dst[r * ldd + c] and dstT[c * ldt + r], so several sources can fill slices of one fused matrix.
+// chain bit 0: dst columns in chain order; bit 1: dstT columns (the source's rows) in chain order.
 __global__ void cast_weights_batch_kernel(const CastItem* __restrict__ items) {
   const CastItem it = items[blockIdx.y];
   const long n = (long)it.R * it.C;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
     const int r = (int)(idx / it.C), c = (int)(idx % it.C);
     const bf16 v = (bf16)it.src[idx];
-    if (it.dst) ((bf16*)it.dst)[(long)r * it.ldd + c] = v;
-    if (it.dstT) ((bf16*)it.dstT)[(long)c * it.ldt + r] = v;
+    if (it.dst) ((bf16*)it.dst)[(long)r * it.ldd + ((it.chain & 1) ? chain_pos(c) : c)] = v;
+    if (it.dstT) ((bf16*)it.dstT)[(long)c * it.ldt + ((it.chain & 2) ? chain_pos(r) : r)] = v;
   }
 }
 

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import FavorPlan, View4, check, lib
+from ._lib import FavorPlan, FfnBwdArgs, FfnFwdArgs, View4, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -150,6 +150,84 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, *, out0: torch.Tensor, o
                           _p(bias), _p(resid), resid.stride(0) if resid is not None else 0,
                           _p(pre), pre.stride(0) if pre is not None else 0, _stream()), "scm_gemm_nt")
     return out0
+
+
+# ----------------------------------------------------------------------------- FeedForward sublayer in one launch
+def chain_pos(n: int) -> torch.Tensor:
+    """position of unit u (u < n) in the chain order in which scm_ffn_chain_* read their second weight (a bit
+    permutation inside every block of 64 units; positions of a last, partial block reach up to its end)"""
+    u = torch.arange(n)
+    v = u & 63
+    return (u & ~63) | (((v >> 2) & 1) << 5) | (((v >> 5) & 1) << 4) | (((v >> 3) & 1) << 3) | (((v >> 4) & 1) << 2) | (v & 3)
+
+
+def chain_copy(w: torch.Tensor) -> torch.Tensor:
+    """[R, F] -> [R, F rounded up to 64] with column u at its chain position, zeros elsewhere"""
+    r, f = w.shape
+    out = torch.zeros((r, (f + 63) // 64 * 64), dtype=w.dtype, device=w.device)
+    out[:, chain_pos(f).to(w.device)] = w
+    return out
+
+
+def ffn_chain_supported(m: int, d: int, f: int) -> bool:
+    return bool(lib.scm_ffn_chain_supported(m, d, f))
+
+
+def ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, *, save: bool, next_ln=None):
+    """x f32 [M,200]; w1 bf16 [F,200]; w2c bf16 [200,F] in chain order.  -> (y f32, tape or None, next or None) with
+    tape = (h, mean, rstd, pre, act) and next = (h_next, mean_next, rstd_next) for next_ln = (gamma, beta)."""
+    _req(x, F32, "x")
+    m, d = x.shape
+    f = w1.shape[0]
+    dev = x.device
+    y = torch.empty((m, d), dtype=F32, device=dev)
+    a = FfnFwdArgs()
+    a.M, a.D, a.F = m, d, f
+    a.x, a.ldx, a.gamma, a.beta = _p(x), x.stride(0), _p(gamma), _p(beta)
+    a.w1, a.ldw1, a.b1, a.w2c, a.ldw2c, a.b2 = _p(w1), w1.stride(0), _p(b1), _p(w2c), w2c.stride(0), _p(b2)
+    tape = None
+    if save:
+        h = torch.empty((m, d), dtype=BF16, device=dev)
+        mean = torch.empty(m, dtype=F32, device=dev)
+        rstd = torch.empty(m, dtype=F32, device=dev)
+        pre = empty_rows(m, f, BF16, dev)
+        act = empty_rows(m, f, BF16, dev)
+        a.h, a.ldh, a.mean, a.rstd = _p(h), h.stride(0), _p(mean), _p(rstd)
+        a.pre, a.ldpre, a.act, a.ldact = _p(pre), pre.stride(0), _p(act), act.stride(0)
+        tape = (h, mean, rstd, pre, act)
+    a.y, a.ldy = _p(y), y.stride(0)
+    nxt = None
+    if next_ln is not None:
+        hn = torch.empty((m, d), dtype=BF16, device=dev)
+        mn = torch.empty(m, dtype=F32, device=dev)
+        rn = torch.empty(m, dtype=F32, device=dev)
+        a.gamma_next, a.beta_next = _p(next_ln[0]), _p(next_ln[1])
+        a.h_next, a.ldh_next, a.mean_next, a.rstd_next = _p(hn), hn.stride(0), _p(mn), _p(rn)
+        nxt = (hn, mn, rn)
+    check(lib.scm_ffn_chain_fwd(C.byref(a), _stream()), "scm_ffn_chain_fwd")
+    return y, tape, nxt
+
+
+def ffn_chain_bwd(dy_b, w2t, w1tc, pre, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool,
+                  with_bf16: bool = True):
+    """-> (dpre bf16 [M,F], dx f32 [M,200], dx bf16 or None)"""
+    m, d = x.shape
+    f = w2t.shape[0]
+    dev = x.device
+    dpre = empty_rows(m, f, BF16, dev)
+    dx = torch.empty((m, d), dtype=F32, device=dev)
+    dxb = torch.empty((m, d), dtype=BF16, device=dev) if with_bf16 else None
+    ws = torch.empty(lib.scm_ffn_chain_ws_floats(m), dtype=F32, device=dev)
+    a = FfnBwdArgs()
+    a.M, a.D, a.F = m, d, f
+    a.dy, a.lddy, a.w2t, a.ldw2t, a.w1tc, a.ldw1tc = _p(dy_b), dy_b.stride(0), _p(w2t), w2t.stride(0), _p(w1tc), w1tc.stride(0)
+    a.pre, a.ldpre, a.dpre, a.lddpre = _p(pre), pre.stride(0), _p(dpre), dpre.stride(0)
+    a.x, a.ldx, a.mean, a.rstd, a.gamma = _p(x), x.stride(0), _p(mean), _p(rstd), _p(gamma)
+    a.dres, a.lddres = _p(dres), (dres.stride(0) if dres is not None else 0)
+    a.dx, a.lddx, a.dx_bf16, a.lddxb = _p(dx), dx.stride(0), _p(dxb), (dxb.stride(0) if dxb is not None else 0)
+    a.ws, a.dgamma, a.dbeta, a.dres_colsum, a.accumulate = _p(ws), _p(dgamma), _p(dbeta), _p(dres_colsum), int(accumulate)
+    check(lib.scm_ffn_chain_bwd(C.byref(a), _stream()), "scm_ffn_chain_bwd")
+    return dpre, dx, dxb
 
 
 def wgrad_slices(t: int, p: int, q_bf16: bool = True) -> int:
