@@ -49,7 +49,7 @@ typedef struct {
   int64_t ldd;
   void* dstT;
   int64_t ldt;
-  int32_t chain; /* bit 0: dst columns, bit 1: dstT columns are written in the chain order of scm_ffn_chain_* */
+  int32_t chain; /* bit 0: dst columns, bit 1: dstT columns are written in the chain order of scm_ffn_chain_fwd */
   int32_t reserved;
 } scm_cast_item;
 int scm_cast_weights_batch(const scm_cast_item* items /* device */, int n, void* stream);
@@ -104,18 +104,16 @@ enum { SCM_EPI_BF16 = 0, SCM_EPI_F32_BIAS_RES = 1, SCM_EPI_GELU_DUAL = 2, SCM_EP
 int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W_bf16, int64_t ldw, int M, int N, int K,
                 void* out0, int64_t ldo0, void* out1, int64_t ldo1, const float* bias, const float* resid,
                 int64_t ldr, const void* pre_bf16, int64_t ldp, void* stream);
-/* ---- the FeedForward sublayer in one launch per direction: PreLayerNorm(Chunk(FeedForward)),
+/* ---- forward of the FeedForward sublayer in one launch: PreLayerNorm(Chunk(FeedForward)),
  *      performer_pytorch.py:289-331, with the residual add of reversible.py:145.  Model dim D = 200 and a hidden
  *      width F % 8 == 0, F <= 2048 (scm_ffn_chain_supported); other sizes use scm_ln_fwd + scm_gemm_nt.
- * The second weight of each direction is read in "chain order": inside every block of 64 along its F index, unit
- * 32 s + 16 e + 8 h + 4 t + i sits at position 32 t + 16 s + 8 h + 4 e + i (bits s,e,h,t; i = 0..3) -- the order in
- * which the first product's accumulators become the second product's operand.  scm_cast_weights_batch writes such
- * copies (scm_cast_item.chain).
- *   forward : y = x + w2 gelu(w1 LN(x) + b1) + b2; optionally h_next = LN_next(y) for the following sublayer.
- *             Saved for the backward when the pointers are given: h = LN(x) (bf16), mean, rstd, pre, act.
- *   backward: dpre = (dy w2) * gelu'(pre) (stored: the w1 weight gradient reads it); dh = dpre w1;
- *             dx = dres + LN'(dh); ws receives scm_ffn_chain_ws_floats(M) floats of column partials that are
- *             reduced into dgamma, dbeta and dres_colsum (the bias gradient of the branch's last Linear). */
+ *   y = x + w2 gelu(w1 LN(x) + b1) + b2; optionally h_next = LN_next(y) for the following sublayer.
+ * The hidden activations stay on the chip between the two products.  The second weight is read in "chain order":
+ * inside every block of 64 along its F index, unit 32 s + 16 e + 8 h + 4 t + i sits at position
+ * 32 t + 16 s + 8 h + 4 e + i (bits s,e,h,t; i = 0..3) -- the order in which the first product's accumulators become
+ * the second product's operand.  scm_cast_weights_batch writes such copies (scm_cast_item.chain).
+ * Written when the pointers are given: h = LN(x) (bf16), mean, rstd, pre, act (the tape of a backward that runs on
+ * scm_gemm_nt / scm_wgrad / scm_ln_bwd).  The product path uses this entry point where no tape is kept. */
 typedef struct {
   int64_t M; int32_t D, F;
   const float* x; int64_t ldx;                 /* f32 [M, D] */
@@ -130,22 +128,8 @@ typedef struct {
   const float* gamma_next; const float* beta_next;         /* optional LayerNorm of y: all five NULL to skip */
   void* h_next; int64_t ldh_next; float* mean_next; float* rstd_next;
 } scm_ffn_fwd_args;
-typedef struct {
-  int64_t M; int32_t D, F;
-  const void* dy; int64_t lddy;                /* bf16 [M, D] gradient of the branch output */
-  const void* w2t; int64_t ldw2t;              /* bf16 [F, D] = w2 transposed */
-  const void* w1tc; int64_t ldw1tc;            /* bf16 [D, Fp] = w1 transposed, chain order, as w2c */
-  const void* pre; int64_t ldpre;              /* bf16 [M, F] saved by the forward */
-  void* dpre; int64_t lddpre;                  /* bf16 [M, F] out */
-  const float* x; int64_t ldx; const float* mean; const float* rstd; const float* gamma;   /* the LayerNorm's tape */
-  const float* dres; int64_t lddres;           /* f32 [M, D] residual gradient, may be NULL */
-  float* dx; int64_t lddx; void* dx_bf16; int64_t lddxb;   /* f32 [M, D]; bf16 copy may be NULL */
-  float* ws; float* dgamma; float* dbeta; float* dres_colsum; int32_t accumulate;  /* dres_colsum may be NULL */
-} scm_ffn_bwd_args;
 int scm_ffn_chain_supported(int64_t M, int D, int F);
-int64_t scm_ffn_chain_ws_floats(int64_t M);
 int scm_ffn_chain_fwd(const scm_ffn_fwd_args* args /* host */, void* stream);
-int scm_ffn_chain_bwd(const scm_ffn_bwd_args* args /* host */, void* stream);
 
 /* Weight gradient: G[P,Q] = sum_t Pm[t,P] * Qm[t,Q]; Pm bf16 (P % 8 == 0), Qm bf16 or (q_f32) f32, Q <= 200,
  * Q % 8 == 0.  grad (+)= G, or G^T when trans (grad is [Q,P]).  bias_grad (may be NULL) (+)= column sums

@@ -36,15 +36,6 @@ class FfnFwdArgs(C.Structure):
                 ("ldh_next", i64), ("mean_next", vp), ("rstd_next", vp)]
 
 
-class FfnBwdArgs(C.Structure):
-    """scm_ffn_bwd_args"""
-    _fields_ = [("M", i64), ("D", i32), ("F", i32), ("dy", vp), ("lddy", i64), ("w2t", vp), ("ldw2t", i64),
-                ("w1tc", vp), ("ldw1tc", i64), ("pre", vp), ("ldpre", i64), ("dpre", vp), ("lddpre", i64),
-                ("x", vp), ("ldx", i64), ("mean", vp), ("rstd", vp), ("gamma", vp), ("dres", vp), ("lddres", i64),
-                ("dx", vp), ("lddx", i64), ("dx_bf16", vp), ("lddxb", i64), ("ws", vp), ("dgamma", vp),
-                ("dbeta", vp), ("dres_colsum", vp), ("accumulate", i32)]
-
-
 # name -> (restype, argtypes); must list every symbol of include/scmomer_hip.h
 SIGNATURES = {
     "scm_version": (i32, []),
@@ -61,9 +52,7 @@ SIGNATURES = {
     "scm_ln_bwd_noalloc": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp]),
     "scm_gemm_nt": (i32, [i32, i32, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]),
     "scm_ffn_chain_supported": (i32, [i64, i32, i32]),
-    "scm_ffn_chain_ws_floats": (i64, [i64]),
     "scm_ffn_chain_fwd": (i32, [C.POINTER(FfnFwdArgs), vp]),
-    "scm_ffn_chain_bwd": (i32, [C.POINTER(FfnBwdArgs), vp]),
     "scm_wgrad_ws_floats": (i64, [i32, i32]),
     "scm_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, i32, i32, vp]),
     "scm_favor_make_plan": (i32, [i32, i32, i32, C.POINTER(FavorPlan)]),

@@ -49,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "ffn_chain_bwd"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -196,9 +196,8 @@ int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W, i
   return 0;
 }
 
-// ---------------------------------------------------------------------------- FeedForward sublayer, chained
+// ---------------------------------------------------------------------------- FeedForward sublayer forward, chained
 int scm_ffn_chain_supported(int64_t M, int D, int F) { return ffn_chain_supported(M, D, F) ? 1 : 0; }
-int64_t scm_ffn_chain_ws_floats(int64_t M) { return M > 0 ? (int64_t)ffn_chain_grid(M) * 3 * 200 : 0; }
 
 int scm_ffn_chain_fwd(const scm_ffn_fwd_args* p, void* stream) {
   SCM_REQ(p, "scm_ffn_chain_fwd: null argument block");
@@ -226,35 +225,7 @@ int scm_ffn_chain_fwd(const scm_ffn_fwd_args* p, void* stream) {
   a.ldo0 = p->ldpre; a.ldo1 = p->ldact; a.y = p->y; a.ldy = p->ldy;
   a.gamma_n = p->gamma_next; a.beta_n = p->beta_next; a.h_n = (bf16*)p->h_next; a.ldhn = p->ldh_next;
   a.mean_n = p->mean_next; a.rstd_n = p->rstd_next;
-  SCM_HIP(ffn_chain(0, a, (hipStream_t)stream), "scm_ffn_chain_fwd");
-  return 0;
-}
-
-int scm_ffn_chain_bwd(const scm_ffn_bwd_args* p, void* stream) {
-  SCM_REQ(p, "scm_ffn_chain_bwd: null argument block");
-  SCM_REQ(ffn_chain_supported(p->M, p->D, p->F), "scm_ffn_chain_bwd: need D = 200, F %% 8 == 0, F <= 2048 (D=%d F=%d)",
-          p->D, p->F);
-  SCM_REQ(p->dy && p->w2t && p->w1tc && p->pre && p->dpre && p->x && p->mean && p->rstd && p->gamma && p->dx && p->ws &&
-              p->dgamma && p->dbeta, "scm_ffn_chain_bwd: null pointer");
-  SCM_REQ(p->lddy >= p->D && p->lddy % 8 == 0 && p->ldw2t >= p->D && p->ldw2t % 8 == 0 && p->ldw1tc >= (p->F + 63) / 64 * 64 &&
-              p->ldw1tc % 8 == 0 && p->ldpre >= p->F && p->ldpre % 8 == 0 && p->lddpre >= p->F && p->lddpre % 8 == 0 &&
-              p->ldx >= p->D && p->ldx % 4 == 0 && p->lddx >= p->D && p->lddx % 4 == 0 &&
-              (!p->dres || (p->lddres >= p->D && p->lddres % 4 == 0)) &&
-              (!p->dx_bf16 || (p->lddxb >= p->D && p->lddxb % 8 == 0)), "scm_ffn_chain_bwd: bad leading dimension");
-  SCM_REQ(aligned16(p->dy) && aligned16(p->w2t) && aligned16(p->w1tc) && aligned16(p->pre) && aligned16(p->dpre) &&
-              aligned16(p->x) && aligned16(p->gamma) && aligned16(p->dx) && (!p->dres || aligned16(p->dres)) &&
-              (!p->dx_bf16 || aligned16(p->dx_bf16)), "scm_ffn_chain_bwd: unaligned pointer");
-  FfnChainArgs a{};
-  a.M = p->M; a.F = p->F; a.W1 = (const bf16*)p->w2t; a.ldw1 = p->ldw2t; a.W2c = (const bf16*)p->w1tc; a.ldw2 = p->ldw1tc;
-  a.x = p->x; a.ldx = p->ldx; a.gamma = p->gamma; a.mean = (float*)p->mean; a.rstd = (float*)p->rstd;
-  a.dy_b = (const bf16*)p->dy; a.lddy = p->lddy; a.pre_in = (const bf16*)p->pre; a.ldp = p->ldpre;
-  a.dpre = (bf16*)p->dpre; a.ldo0 = p->lddpre; a.dres = p->dres; a.lddres = p->lddres; a.dx = p->dx; a.lddx = p->lddx;
-  a.dx_b = (bf16*)p->dx_bf16; a.lddxb = p->lddxb; a.partial = p->ws;
-  hipStream_t s = (hipStream_t)stream;
-  SCM_HIP(ffn_chain(1, a, s), "scm_ffn_chain_bwd");
-  const int D = 200;
-  const ColsumSegs seg{{p->dgamma, p->dbeta, p->dres_colsum, nullptr}, {0, D, 2 * D, 0}, {D, 2 * D, 3 * D, 0}};
-  SCM_HIP(colsum_reduce(p->ws, ffn_chain_grid(p->M), 3 * D, seg, 3, p->accumulate, s), "scm_ffn_chain_bwd(column sums)");
+  SCM_HIP(ffn_chain(a, (hipStream_t)stream), "scm_ffn_chain_fwd");
   return 0;
 }
 

@@ -79,7 +79,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
   K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_BIN, K_OMEGA_QR, K_FEATURE_MAP, K_LINEAR_ATTENTION, K_FFN_CHAIN_FWD,
-  K_FFN_CHAIN_BWD, K_COUNT
+  K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
@@ -102,31 +102,23 @@ hipError_t cast_weight(const float* src, int R, int C, void* dst, void* dstT, hi
 using CastItem = ::scm_cast_item;   // the C ABI's table entry
 hipError_t cast_weights_batch(const CastItem* items, int n, hipStream_t s);
 
-// ffn_chain.hip: the FeedForward sublayer as one kernel per direction (model dim 200, hidden width % 8 == 0)
+// ffn_chain.hip: forward of the FeedForward sublayer as one kernel (model dim 200, hidden width % 8 == 0)
 struct FfnChainArgs {
   long M; int F;
-  const bf16* W1; long ldw1;      // first product: [F, 200] (forward w1; backward w2 transposed)
-  const bf16* W2c; long ldw2;     // second product: [200, F] in chain k order (forward w2; backward w1 transposed)
-  const float* x; long ldx;       // f32 [M, 200]: forward input = residual; backward the LayerNorm's input
-  const float* gamma; const float* beta;   // LayerNorm of the sublayer (backward: gamma only)
-  float* mean; float* rstd;       // forward out (may be null), backward in
-  // forward
+  const bf16* W1; long ldw1;      // first product: w1 [F, 200]
+  const bf16* W2c; long ldw2;     // second product: w2 [200, F padded to 64] in chain k order
+  const float* x; long ldx;       // f32 [M, 200]: input = residual
+  const float* gamma; const float* beta;   // LayerNorm of the sublayer
+  float* mean; float* rstd;       // out (may be null)
   const float* bias1; const float* bias2;
-  bf16* h; long ldh;              // LayerNorm output, saved for the weight gradient (may be null)
-  bf16* pre; bf16* act; long ldo0, ldo1;   // hidden pre-activation / activation (may be null); backward: ldo0 = dpre pitch
+  bf16* h; long ldh;              // LayerNorm output (may be null)
+  bf16* pre; bf16* act; long ldo0, ldo1;   // hidden pre-activation / activation (may be null)
   float* y; long ldy;
   const float* gamma_n; const float* beta_n; bf16* h_n; long ldhn; float* mean_n; float* rstd_n;  // optional LN of y
-  // backward
-  const bf16* dy_b; long lddy;    // bf16 [M, 200]
-  const bf16* pre_in; long ldp;
-  bf16* dpre;
-  const float* dres; long lddres; // f32 [M, 200] residual gradient (may be null)
-  float* dx; long lddx; bf16* dx_b; long lddxb;
-  float* partial;                 // [grid][3][200]: dgamma, dbeta, column sums of dres
 };
 int ffn_chain_grid(long M);
 bool ffn_chain_supported(long M, int D, int F);
-hipError_t ffn_chain(int mode, FfnChainArgs a, hipStream_t s);
+hipError_t ffn_chain(FfnChainArgs a, hipStream_t s);
 
 // norm_embed.hip
 hipError_t embed_fwd(const int64_t* tok, const float* E, const double* G, int B, int N, int D, int V, float* out,

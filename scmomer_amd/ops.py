@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import FavorPlan, FfnBwdArgs, FfnFwdArgs, View4, check, lib
+from ._lib import FavorPlan, FfnFwdArgs, View4, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -154,7 +154,7 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, *, out0: torch.Tensor, o
 
 # ----------------------------------------------------------------------------- FeedForward sublayer in one launch
 def chain_pos(n: int) -> torch.Tensor:
-    """position of unit u (u < n) in the chain order in which scm_ffn_chain_* read their second weight (a bit
+    """position of unit u (u < n) in the chain order in which scm_ffn_chain_fwd reads its second weight (a bit
     permutation inside every block of 64 units; positions of a last, partial block reach up to its end)"""
     u = torch.arange(n)
     v = u & 63
@@ -206,28 +206,6 @@ def ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, *, save: bool, next_ln=None):
         nxt = (hn, mn, rn)
     check(lib.scm_ffn_chain_fwd(C.byref(a), _stream()), "scm_ffn_chain_fwd")
     return y, tape, nxt
-
-
-def ffn_chain_bwd(dy_b, w2t, w1tc, pre, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool,
-                  with_bf16: bool = True):
-    """-> (dpre bf16 [M,F], dx f32 [M,200], dx bf16 or None)"""
-    m, d = x.shape
-    f = w2t.shape[0]
-    dev = x.device
-    dpre = empty_rows(m, f, BF16, dev)
-    dx = torch.empty((m, d), dtype=F32, device=dev)
-    dxb = torch.empty((m, d), dtype=BF16, device=dev) if with_bf16 else None
-    ws = torch.empty(lib.scm_ffn_chain_ws_floats(m), dtype=F32, device=dev)
-    a = FfnBwdArgs()
-    a.M, a.D, a.F = m, d, f
-    a.dy, a.lddy, a.w2t, a.ldw2t, a.w1tc, a.ldw1tc = _p(dy_b), dy_b.stride(0), _p(w2t), w2t.stride(0), _p(w1tc), w1tc.stride(0)
-    a.pre, a.ldpre, a.dpre, a.lddpre = _p(pre), pre.stride(0), _p(dpre), dpre.stride(0)
-    a.x, a.ldx, a.mean, a.rstd, a.gamma = _p(x), x.stride(0), _p(mean), _p(rstd), _p(gamma)
-    a.dres, a.lddres = _p(dres), (dres.stride(0) if dres is not None else 0)
-    a.dx, a.lddx, a.dx_bf16, a.lddxb = _p(dx), dx.stride(0), _p(dxb), (dxb.stride(0) if dxb is not None else 0)
-    a.ws, a.dgamma, a.dbeta, a.dres_colsum, a.accumulate = _p(ws), _p(dgamma), _p(dbeta), _p(dres_colsum), int(accumulate)
-    check(lib.scm_ffn_chain_bwd(C.byref(a), _stream()), "scm_ffn_chain_bwd")
-    return dpre, dx, dxb
 
 
 def wgrad_slices(t: int, p: int, q_bf16: bool = True) -> int:

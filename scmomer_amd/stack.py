@@ -100,7 +100,11 @@ class WeightCache:
                                          out=(old["w1"], old["w1_t"]) if old else None)
             w2_b, w2_t = ops.cast_weight(p["w2"].detach().to(F32).contiguous(),
                                          out=(old["w2"], old["w2_t"]) if old else None)
-        out = {"w1": w1_b, "w1_t": w1_t, "w2": w2_b, "w2_t": w2_t, "device": ver[0]}
+            # w2 with its hidden index in the order the one-launch forward reads it (no-tape path)
+            w2_c = ops.chain_copy(w2_b)
+            if old is not None:
+                w2_c = old["w2_c"].copy_(w2_c)
+        out = {"w1": w1_b, "w1_t": w1_t, "w2": w2_b, "w2_t": w2_t, "w2_c": w2_c, "device": ver[0]}
         self.store[("f", key)] = (ver, out)
         return out
 
@@ -125,19 +129,22 @@ def _cast_table(cache: WeightCache, layers) -> Optional[Tuple[torch.Tensor, int,
             return None
         wa, wf = ha[1], hf[1]
         inner, d = ap["wq"].shape
-        srcs = [(ap["wq"], wa["wqkv"], 0, d, wa["wqkv_t"], 0, 3 * inner),
-                (ap["wk"], wa["wqkv"], inner * d, d, wa["wqkv_t"], inner, 3 * inner),
-                (ap["wv"], wa["wqkv"], 2 * inner * d, d, wa["wqkv_t"], 2 * inner, 3 * inner),
-                (ap["wo"], wa["wo"], 0, inner, wa["wo_t"], 0, d),
-                (fp["w1"], wf["w1"], 0, d, wf["w1_t"], 0, fp["w1"].shape[0]),
-                (fp["w2"], wf["w2"], 0, fp["w2"].shape[1], wf["w2_t"], 0, d)]
-        for src, dst, dst_off, ldd, dstt, dstt_off, ldt in srcs:
-            if src.dtype != F32 or not src.is_contiguous() or not dst.is_contiguous() or not dstt.is_contiguous():
+        srcs = [(ap["wq"], wa["wqkv"], 0, d, wa["wqkv_t"], 0, 3 * inner, 0),
+                (ap["wk"], wa["wqkv"], inner * d, d, wa["wqkv_t"], inner, 3 * inner, 0),
+                (ap["wv"], wa["wqkv"], 2 * inner * d, d, wa["wqkv_t"], 2 * inner, 3 * inner, 0),
+                (ap["wo"], wa["wo"], 0, inner, wa["wo_t"], 0, d, 0),
+                (fp["w1"], wf["w1"], 0, d, wf["w1_t"], 0, fp["w1"].shape[0], 0),
+                (fp["w2"], wf["w2"], 0, fp["w2"].shape[1], wf["w2_t"], 0, d, 0),
+                (fp["w2"], wf["w2_c"], 0, wf["w2_c"].shape[1], None, 0, 0, 1)]   # chain-order copy
+        for src, dst, dst_off, ldd, dstt, dstt_off, ldt, chain in srcs:
+            if src.dtype != F32 or not src.is_contiguous() or not dst.is_contiguous() or \
+                    (dstt is not None and not dstt.is_contiguous()):
                 return None
             r, c = src.shape
-            rows.append(struct.pack("<QiiQqQq", src.data_ptr(), r, c, dst.data_ptr() + 2 * dst_off, ldd,
-                                    dstt.data_ptr() + 2 * dstt_off, ldt))
-            ptrs.append(src.data_ptr())
+            rows.append(struct.pack("<QiiQqQqii", src.data_ptr(), r, c, dst.data_ptr() + 2 * dst_off, ldd,
+                                    dstt.data_ptr() + 2 * dstt_off if dstt is not None else 0, ldt, chain, 0))
+            if chain == 0:
+                ptrs.append(src.data_ptr())
     if not rows:
         return None
     table = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(layers[0][0]["wq"].device)
@@ -205,14 +212,18 @@ def _qkv_views(qkv5):
     return tuple(qkv5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
 
 
-def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool):
-    """x: f32 [B,N,D].  Returns (y f32 [B,N,D] = resid + to_out(attn(LN(x))) + bias, tape)."""
+def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool,
+             pre_ln: Optional[tuple] = None):
+    """x: f32 [B,N,D].  Returns (y f32 [B,N,D] = resid + to_out(attn(LN(x))) + bias, tape).
+    pre_ln: (h, mean, rstd) when the producer of x already applied this sublayer's LayerNorm."""
     b, n, d = x.shape
     t = b * n
     heads = p["heads"]
     inner = heads * ops.DIM_HEAD
     x2 = x.reshape(t, d)
-    if ln:
+    if pre_ln is not None:
+        h, mean, rstd = pre_ln
+    elif ln:
         h, mean, rstd = ops.ln_fwd(x2, p["g1"], p["b1"])
     else:
         h, mean, rstd = x2.to(BF16), None, None
@@ -393,11 +404,22 @@ class _StackFn(torch.autograd.Function):
         else:
             tokens = None
             x = inp.to(F32).contiguous()
+        pre_ln = None
         for li, (ap, fp) in enumerate(spec.layers):
             aw = spec.cache.attn(li, ap)
             fw = spec.cache.ffn(li, fp)
-            x1, at = attn_fwd(x, ap, aw, ln=True, resid=x, save=spec.save)
-            x2, ft = ffn_fwd(x1, fp, fw, ln=True, resid=x1, save=spec.save)
+            x1, at = attn_fwd(x, ap, aw, ln=True, resid=x, save=spec.save, pre_ln=pre_ln)
+            pre_ln = None
+            b_, n_, d_ = x1.shape
+            if not spec.save and fp["c1"] is not None and ops.ffn_chain_supported(b_ * n_, d_, fp["w1"].shape[0]):
+                # no tape: the whole FeedForward sublayer in one launch, which also applies the next layer's LayerNorm
+                nxt = spec.layers[li + 1][0] if li + 1 < len(spec.layers) else None
+                y, _, pre_ln = ops.ffn_chain_fwd(x1.reshape(b_ * n_, d_), fp["g2"], fp["b2"], fw["w1"], fp["c1"], fw["w2_c"],
+                                                 fp["c2"], save=False,
+                                                 next_ln=(nxt["g1"], nxt["b1"]) if nxt is not None else None)
+                x2, ft = y.view(b_, n_, d_), None
+            else:
+                x2, ft = ffn_fwd(x1, fp, fw, ln=True, resid=x1, save=spec.save)
             tapes.append((at, ft))
             x = x2
         ctx.spec, ctx.tapes, ctx.tokens = spec, tapes, tokens

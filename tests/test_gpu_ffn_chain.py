@@ -1,5 +1,5 @@
-"""GPU parity of the one-launch FeedForward sublayer (scm_ffn_chain_fwd / scm_ffn_chain_bwd) through the C ABI:
-against the separate kernels it replaces (LayerNorm, the two Linear products, LayerNorm backward) and against an
+"""GPU parity of the one-launch FeedForward sublayer forward (scm_ffn_chain_fwd) through the C ABI:
+against the separate kernels it replaces (LayerNorm, the two Linear products) and against an
 fp32 torch restatement of PreLayerNorm(Chunk(FeedForward)) + residual (performer_pytorch.py:289-331,
 reversible.py:145)."""
 import pytest
@@ -24,9 +24,7 @@ def _setup(m, seed=0):
     w1b, w1t = ops.cast_weight(w1)
     w2b, w2t = ops.cast_weight(w2)
     w2c = ops.chain_copy(w2b)
-    w1tc = ops.chain_copy(w1t)
-    return dict(x=x, gamma=gamma, beta=beta, w1=w1, b1=b1, w2=w2, b2=b2, w1b=w1b, w1t=w1t, w2b=w2b, w2t=w2t, w2c=w2c,
-                w1tc=w1tc)
+    return dict(x=x, gamma=gamma, beta=beta, w1=w1, b1=b1, w2=w2, b2=b2, w1b=w1b, w1t=w1t, w2b=w2b, w2t=w2t, w2c=w2c)
 
 
 def _separate_fwd(p):
@@ -82,39 +80,43 @@ def test_forward_without_tape_writes_only_y():
     assert torch.equal(y, y1)
 
 
-@pytest.mark.parametrize("m", [1, 31, 257, 5000, 50718])
-def test_backward_matches_separate_kernels_and_fp32(m):
-    from scmomer_amd import ops
-    p = _setup(m, seed=100 + m)
-    h, mean, rstd, pre, act, y = _separate_fwd(p)
-    dy = (torch.randn(m, D, generator=torch.Generator().manual_seed(m)) * 0.02).cuda()
-    dyb = dy.to(torch.bfloat16)
-    # separate kernels
-    dpre0 = ops.empty_rows(m, F, torch.bfloat16, "cuda")
-    ops.gemm_nt(ops.EPI_DGELU, dyb, p["w2t"], out0=dpre0, pre=pre)
-    dh0 = torch.empty(m, D, device="cuda")
-    ops.gemm_nt(ops.EPI_F32, dpre0, p["w1t"], out0=dh0)
-    g0, b0, c0 = (torch.empty(D, device="cuda") for _ in range(3))
-    dx0, dxb0 = ops.ln_bwd(dh0, p["x"], mean, rstd, p["gamma"], dy, g0, b0, c0, False, True)
-    # one launch
-    g1, b1, c1 = (torch.empty(D, device="cuda") for _ in range(3))
-    dpre, dx, dxb = ops.ffn_chain_bwd(dyb, p["w2t"], p["w1tc"], pre, p["x"], mean, rstd, p["gamma"], dy, g1, b1, c1, False)
+def _small_model(n=700, depth=2):
+    import numpy as np
+    import scmomer_amd as S
+    from oracle import performer_oracle as O
+    p = O.make_params(3, depth=depth, max_seq_len=n)
+    m = S.PerformerLM(num_tokens=7, dim=200, depth=depth, max_seq_len=n, heads=10, local_attn_heads=0)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    tokens = torch.from_numpy(np.random.default_rng(4).integers(0, 6, (2, n)).astype("int64")).cuda()
+    return m, tokens
+
+
+def test_model_without_tape_matches_the_taped_forward():
+    """no_grad runs the FeedForward sublayers through the one-launch kernel (and its fused next LayerNorm); with
+    gradients enabled the separate kernels run.  Same weights, same inputs: the outputs agree to bf16 rounding."""
+    m, tokens = _small_model()
+    with torch.no_grad():
+        a = m(tokens)
+        ea = m(tokens, return_encodings=True)
+    with torch.enable_grad():
+        b = m(tokens).detach()
+        eb = m(tokens, return_encodings=True).detach()
     torch.cuda.synchronize()
-    assert torch.equal(dpre, dpre0)                      # same products, same order
-    scale = dx0.abs().max().item()
-    assert (dx - dx0).abs().max().item() <= 2e-3 * scale, ((dx - dx0).abs().max().item(), scale)
-    assert (dxb.float() - dx).abs().max().item() <= 2 ** -8 * scale
-    for a_, b_ in ((g1, g0), (b1, b0), (c1, c0)):
-        assert torch.allclose(a_, b_, atol=2e-3 * max(b_.abs().max().item(), 1e-3), rtol=0), (a_ - b_).abs().max()
-    # fp32/fp64 autograd restatement of the data path (dy treated exactly)
-    xr = p["x"].double().requires_grad_(True)
-    gam = p["gamma"].double().requires_grad_(True)
-    bet = p["beta"].double().requires_grad_(True)
-    hr = torch.nn.functional.layer_norm(xr, (D,), gam, bet, 1e-5)
-    yr = xr + torch.nn.functional.gelu(hr @ p["w1"].double().t() + p["b1"].double()) @ p["w2"].double().t()
-    yr.backward(dy.double())
-    rel = ((dx.double() - xr.grad).norm() / xr.grad.norm()).item()
-    assert rel <= 6e-3, rel
-    assert ((g1.double() - gam.grad).norm() / gam.grad.norm()).item() <= 2e-2
-    assert ((b1.double() - bet.grad).norm() / bet.grad.norm()).item() <= 2e-2
-    assert torch.allclose(c1.double(), dy.double().sum(0), atol=1e-4 * m ** 0.5 + 1e-5, rtol=1e-4)
+    assert (a - b).abs().max().item() <= 4e-3 * b.abs().max().item(), (a - b).abs().max().item()
+    assert (ea - eb).abs().max().item() <= 4e-3 * eb.abs().max().item()
+
+
+def test_weight_refresh_rewrites_the_chain_copy():
+    from scmomer_amd import ops, stack
+    m, tokens = _small_model(n=300, depth=1)
+    with torch.no_grad():
+        m(tokens)                                   # creates the copies
+        stack.refresh_weights(m)                    # builds the one-launch refresh table
+        w2 = m.performer.net.layers[0][1].fn.fn.w2.weight
+        w2.add_(0.01 * torch.randn_like(w2))        # bumps the version, as an optimizer step does
+        stack.refresh_weights(m)
+        cache = stack._cache_of(m).store[("f", 0)][1]
+        torch.cuda.synchronize()
+        assert torch.equal(cache["w2_c"], ops.chain_copy(w2.to(torch.bfloat16)))
+        assert torch.equal(cache["w2"], w2.to(torch.bfloat16))

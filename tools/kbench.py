@@ -116,11 +116,11 @@ if filt == "wpair":
     for name, a, b in (("ffn pair (w1+bias, w2)", A, B), ("attn pair (qkv, wo)", Cq, Do)):
         print(f"{name:28s} sequential {timeit(lambda: seq(a, b)) * 1e6:7.1f} us   two streams {timeit(lambda: par(a, b)) * 1e6:7.1f} us")
 
-# ---- FeedForward sublayer in one launch per direction against the kernels it replaces (filter "chain")
+# ---- FeedForward sublayer forward in one launch against the kernels it replaces (filter "chain")
 if filt == "chain":
     x = rnd(T, D, dtype=f32); gamma = torch.ones(D, device=dev); beta = torch.zeros(D, device=dev)
     w1 = rnd(F, D); w2 = rnd(D, F); b1 = rnd(F, dtype=f32); b2 = rnd(D, dtype=f32)
-    w2c = ops.chain_copy(w2); w1tc = ops.chain_copy(w1.t().contiguous()); w2t = w2.t().contiguous(); w1t = w1.t().contiguous()
+    w2c = ops.chain_copy(w2)
     def sep_fwd():
         h, mean, rstd = ops.ln_fwd(x, gamma, beta)
         pre = ops.empty_rows(T, F, bf, dev); act = ops.empty_rows(T, F, bf, dev)
@@ -128,18 +128,7 @@ if filt == "chain":
         y = torch.empty_like(x)
         ops.gemm_nt(ops.EPI_F32_BIAS_RES, act, w2, out0=y, bias=b2, resid=x)
         return ops.ln_fwd(y, gamma, beta)
-    y, tape, nxt = ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=True, next_ln=(gamma, beta))
-    h, mean, rstd, pre, act = tape
-    dy = rnd(T, D, dtype=f32); dyb = dy.to(bf)
-    gg, gb, gc = (torch.empty(D, device=dev) for _ in range(3))
-    def sep_bwd():
-        dpre = ops.empty_rows(T, F, bf, dev)
-        ops.gemm_nt(ops.EPI_DGELU, dyb, w2t, out0=dpre, pre=pre)
-        dh = torch.empty(T, D, device=dev)
-        ops.gemm_nt(ops.EPI_F32, dpre, w1t, out0=dh)
-        return ops.ln_bwd(dh, x, mean, rstd, gamma, dy, gg, gb, gc, False, True)
-    print(f"forward  separate (ln, ffn1, ffn2, next ln) {timeit(sep_fwd) * 1e6:7.1f} us")
-    print(f"forward  one launch (saving tape, next ln)  {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=True, next_ln=(gamma, beta))) * 1e6:7.1f} us")
-    print(f"forward  one launch (no tape)               {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=False)) * 1e6:7.1f} us")
-    print(f"backward separate (dgelu, dh, ln_bwd)       {timeit(sep_bwd) * 1e6:7.1f} us")
-    print(f"backward one launch                         {timeit(lambda: ops.ffn_chain_bwd(dyb, w2t, w1tc, pre, x, mean, rstd, gamma, dy, gg, gb, gc, False)) * 1e6:7.1f} us")
+    print(f"separate (ln, ffn1, ffn2, next ln)          {timeit(sep_fwd) * 1e6:7.1f} us")
+    print(f"one launch (saving tape, next ln)           {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=True, next_ln=(gamma, beta))) * 1e6:7.1f} us")
+    print(f"one launch (no tape, next ln)               {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=False, next_ln=(gamma, beta))) * 1e6:7.1f} us")
+    print(f"one launch (no tape)                        {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=False)) * 1e6:7.1f} us")
