@@ -32,7 +32,7 @@ PEAK_HBM_GBS = 8000.0              # MI355X HBM3E
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grad-acc", type=int, default=5, help="micro-steps per optimizer step (README uses 5)")
     ap.add_argument("--batch", type=int, default=BATCH)
@@ -125,7 +125,27 @@ TRACE_SYMBOL = {"favor_apply_fwd": "favor_apply_kernel<0>", "favor_apply_bwd_q":
                 "favor_ctx_bwd": "favor_ctx_kernel<1>", "wgrad": "wgrad_dma_kernel<false>",
                 "wgrad/bias": "wgrad_dma_kernel<true>", "gemm_nt/f32_bias_res": "gemm_nt_dma_kernel<1>",
                 "gemm_nt/f32": "gemm_nt_dma_kernel<4>", "gemm_skinny/bf16": "gemm_skinny_kernel<false, 0>",
-                "gemm_skinny/gelu_dual": "gemm_skinny_kernel<false, 2>", "gemm_skinny/dgelu": "gemm_skinny_kernel<false, 3>"}
+                "gemm_skinny/gelu_dual": "gemm_skinny_kernel<false, 2>", "gemm_skinny/dgelu": "gemm_skinny_kernel<false, 3>",
+                "ffn_chain_fwd": "ffn_chain_kernel"}
+HBM_ACHIEVABLE_GBS = 6290.0   # float4 streaming copy on this part (measured ceiling; the datasheet peak is 8000)
+
+
+def measured_utilisation(kernel, pattern="r*_pmc_mfma_valu_summary.txt"):
+    """(matrix-core utilisation, vector-ALU busy share) of `kernel` from the committed rocprofv3 counter passes
+    (SQ_VALU_MFMA_BUSY_CYCLES and SQ_ACTIVE_INST_VALU over kernel cycles x SIMDs), or (None, None)."""
+    import glob
+    sym = TRACE_SYMBOL.get(kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not sym or not files:
+        return None, None, None
+    for ln in open(files[-1]).read().splitlines():
+        if ln.startswith(sym + " ") or ln.startswith(sym[:44] + " "):
+            cols = ln[len(sym):].split()
+            try:
+                return float(cols[2]), float(cols[3]), os.path.basename(files[-1])
+            except (IndexError, ValueError):
+                break
+    return None, None, None
 
 
 def measured_traffic(kernel, pattern="r*_pmc_fetch_write_summary.txt"):
@@ -498,12 +518,18 @@ def main():
         bound = "mfma" if by <= 0 or fl / by >= ridge else "hbm"
         tflops, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dominant)
+        mfma_util, valu_busy, util_src = measured_utilisation(dominant)
+        step_bytes = sum(v[3] for v in trace.values()) / traced_steps
         roof = {"bound": bound, "kernel": dominant,
                 "achieved": tflops if bound == "mfma" else gbs,
                 "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                 "frac": tflops / PEAK_BF16_TFLOPS if bound == "mfma" else gbs / PEAK_HBM_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
+                "hbm_achievable_gbs": HBM_ACHIEVABLE_GBS, "frac_of_achievable_hbm": gbs / HBM_ACHIEVABLE_GBS,
+                "mfma_util": mfma_util, "valu_busy": valu_busy, "utilisation_source": util_src,
+                "algorithmic_bytes_per_step_all_kernels": step_bytes,
+                "algorithmic_bytes_per_step_lower_bound": 365e6 * args.batch,
                 "avg_launch_ms": ms / cnt, "launches_per_step": cnt / traced_steps,
                 "algorithmic_bytes_per_launch": by / cnt, "algorithmic_flops_per_launch": fl / cnt,
                 "tflops": tflops, "gbs": gbs, "share_of_kernel_time": ms / sum(v[0] for v in trace.values()),
