@@ -61,7 +61,8 @@ int scm_prep_omega(const float* omega, void* omega_b, void* stream);
  * *err (device int, caller-zeroed) is set to 1 if a token id is outside [0,V). */
 int scm_embed_fwd(const int64_t* tok, const float* E, const double* G, int B, int N, int D, int V, float* out,
                   int* err, void* stream);
-/* dE[v,:] (+)= sum of dx rows whose token id is v.  ws: scm_embed_bwd_ws_floats(T,D,V) floats. */
+/* dE[v,:] (+)= sum of dx rows whose token id is v.  ws: scm_embed_bwd_ws_floats(T,D,V) floats.
+ * dE may be NULL: then the per-workgroup partial rows [blocks][V*D] stay in ws for scm_reduce_batch. */
 int64_t scm_embed_bwd_ws_floats(int64_t T, int D, int V);
 int scm_embed_bwd(const int64_t* tok, const float* dx, int64_t T, int D, int V, float* ws, float* dE, int accumulate,
                   void* stream);
@@ -135,8 +136,28 @@ int scm_ffn_chain_fwd(const scm_ffn_fwd_args* args /* host */, void* stream);
  * Q % 8 == 0.  grad (+)= G, or G^T when trans (grad is [Q,P]).  bias_grad (may be NULL) (+)= column sums
  * of Pm.  ws: scm_wgrad_ws_floats(P, slices) floats; slices token slices are reduced in a fixed order. */
 int64_t scm_wgrad_ws_floats(int P, int slices);
+/* grad may be NULL: then only the slice partials are left in ws ([slices][P][208] f32, the bias column at index Q
+ * when bias_grad is not NULL) for a later scm_reduce_batch. */
 int scm_wgrad(const void* Pm_bf16, int64_t ldp, const void* Qm, int64_t ldq, int q_f32, int64_t T, int P, int Q,
               int slices, float* ws, float* grad, float* bias_grad, int trans, int accumulate, void* stream);
+
+/* ---- deferred reductions: one launch for the small reductions that end the gradient kernels ----------------
+ * A backward pass runs some forty of them (24 weight-gradient slab sums, 14 column sums); each is a few microseconds
+ * of launch and drain.  The producing entry points can leave their partials in the workspace (scm_wgrad with
+ * grad == NULL; scm_ln_bwd / scm_head_bwd / scm_embed_bwd with NULL gradient outputs) and one call sums them all, each
+ * element in the same fixed order as the immediate reduction (bit-identical results).
+ *   kind 0  weight-gradient slabs: src = ws of scm_wgrad, S slices, out0 (+)= sum (transposed when trans),
+ *           out1 (may be NULL) (+)= the bias column;
+ *   kind 1  column partials: src = [S][P] rows (P = row width); out_k[i] (+)= sum_s src[s][lo[k] + i], i < hi[k] - lo[k],
+ *           for the outputs that are not NULL. */
+typedef struct {
+  int32_t kind, accumulate;
+  const float* src;
+  int32_t S, P, Q, trans;
+  float* out[4];
+  int32_t lo[4], hi[4];
+} scm_reduce_job;
+int scm_reduce_batch(const scm_reduce_job* jobs /* host */, int n, void* stream);
 
 /* ---- FAVOR+ attention: FastAttention.forward performer_pytorch.py:233-250 =
  *      softmax_kernel (:67-92, query and key modes) + linear_attention (:144-149) --------------- */

@@ -27,6 +27,12 @@ class FavorPlan(C.Structure):
 vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
 
 
+class ReduceJob(C.Structure):
+    """scm_reduce_job"""
+    _fields_ = [("kind", i32), ("accumulate", i32), ("src", vp), ("S", i32), ("P", i32), ("Q", i32), ("trans", i32),
+                ("out", vp * 4), ("lo", i32 * 4), ("hi", i32 * 4)]
+
+
 class FfnFwdArgs(C.Structure):
     """scm_ffn_fwd_args"""
     _fields_ = [("M", i64), ("D", i32), ("F", i32), ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp),
@@ -51,6 +57,7 @@ SIGNATURES = {
     "scm_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "scm_ln_bwd_noalloc": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp]),
     "scm_gemm_nt": (i32, [i32, i32, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]),
+    "scm_reduce_batch": (i32, [C.POINTER(ReduceJob), i32, vp]),
     "scm_ffn_chain_supported": (i32, [i64, i32, i32]),
     "scm_ffn_chain_fwd": (i32, [C.POINTER(FfnFwdArgs), vp]),
     "scm_wgrad_ws_floats": (i64, [i32, i32]),

@@ -49,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -126,11 +126,12 @@ int64_t scm_embed_bwd_ws_floats(int64_t T, int D, int V) { return (int64_t)embed
 
 int scm_embed_bwd(const int64_t* tok, const float* dx, int64_t T, int D, int V, float* ws, float* dE, int accumulate,
                   void* stream) {
-  SCM_REQ(tok && dx && ws && dE, "scm_embed_bwd: null pointer");
+  SCM_REQ(tok && dx && ws, "scm_embed_bwd: null pointer");
   SCM_REQ(T > 0 && D > 0 && D <= 256 && D % 4 == 0 && V > 0 && V <= 8, "scm_embed_bwd: bad sizes");
   SCM_HIP(embed_bwd(tok, dx, T, D, V, ws, (hipStream_t)stream), "scm_embed_bwd");
-  SCM_HIP(colsum_reduce(ws, embed_bwd_blocks(T), V * D, 0, V * D, dE, accumulate, (hipStream_t)stream),
-          "scm_embed_bwd(reduce)");
+  if (dE)
+    SCM_HIP(colsum_reduce(ws, embed_bwd_blocks(T), V * D, 0, V * D, dE, accumulate, (hipStream_t)stream),
+            "scm_embed_bwd(reduce)");
   return 0;
 }
 
@@ -233,14 +234,32 @@ int64_t scm_wgrad_ws_floats(int P, int slices) { return (int64_t)slices * P * W_
 
 int scm_wgrad(const void* Pm, int64_t ldp, const void* Qm, int64_t ldq, int q_f32, int64_t T, int P, int Q,
               int slices, float* ws, float* grad, float* bias_grad, int trans, int accumulate, void* stream) {
-  SCM_REQ(Pm && Qm && ws && grad, "scm_wgrad: null pointer");
+  SCM_REQ(Pm && Qm && ws, "scm_wgrad: null pointer");
   SCM_REQ(T > 0 && T < (1ll << 31) && P > 0 && P % 8 == 0 && Q > 0 && Q <= 200 && Q % 8 == 0 && slices > 0,
           "scm_wgrad: need P%%8==0, Q<=200, Q%%8==0 (P=%d Q=%d)", P, Q);
   SCM_REQ(ldp % 8 == 0 && ldp >= P && ldq >= Q && ldq % 8 == 0 && aligned16(Pm) && aligned16(Qm),
           "scm_wgrad: bad leading dimension or alignment");
   hipStream_t s = (hipStream_t)stream;
   SCM_HIP(wgrad(Pm, ldp, Qm, ldq, q_f32, bias_grad ? 1 : 0, (int)T, P, Q, slices, ws, s), "scm_wgrad");
-  SCM_HIP(wgrad_reduce(ws, slices, P, Q, grad, bias_grad, trans, accumulate, s), "scm_wgrad(reduce)");
+  if (grad) SCM_HIP(wgrad_reduce(ws, slices, P, Q, grad, bias_grad, trans, accumulate, s), "scm_wgrad(reduce)");
+  return 0;
+}
+
+int scm_reduce_batch(const scm_reduce_job* jobs, int n, void* stream) {
+  SCM_REQ(jobs && n > 0, "scm_reduce_batch: no jobs");
+  for (int i = 0; i < n; ++i) {
+    const scm_reduce_job& j = jobs[i];
+    SCM_REQ(j.src && j.S > 0 && j.P > 0, "scm_reduce_batch: job %d: null source or empty shape", i);
+    if (j.kind == 0) {
+      SCM_REQ(j.out[0] && j.Q > 0 && j.Q <= 200, "scm_reduce_batch: job %d: slab job needs out[0] and 0 < Q <= 200", i);
+    } else {
+      SCM_REQ(j.kind == 1, "scm_reduce_batch: job %d: kind is 0 or 1", i);
+      for (int k = 0; k < 4; ++k)
+        SCM_REQ(!j.out[k] || (j.lo[k] >= 0 && j.hi[k] > j.lo[k] && j.hi[k] <= j.P),
+                "scm_reduce_batch: job %d: segment %d outside the row", i, k);
+    }
+  }
+  SCM_HIP(reduce_batch(jobs, n, (hipStream_t)stream), "scm_reduce_batch");
   return 0;
 }
 

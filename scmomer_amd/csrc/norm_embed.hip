@@ -351,7 +351,96 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
   }
 }
 
+// Every small reduction of a backward pass in one launch (blockIdx.y = job).  Each element is summed exactly as
+// wgrad_reduce_kernel / colsum_reduce_kernel sum it, so deferring a reduction does not change a bit of the result.
+struct ReduceJobs { ReduceJob job[RB_MAX]; };
+__global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceJobs jobs) {
+  __shared__ float red[32][33];
+  const ReduceJob& j = jobs.job[blockIdx.y];
+  if (j.kind == 0) {
+    const int P = j.P, Q = j.Q, S = j.S;
+    float* __restrict__ grad = j.out[0];
+    float* __restrict__ bias = j.out[1];
+    const int qn = bias ? Q + 1 : Q;
+    const long st = (long)P * W_LDSLAB;
+    for (int idx = blockIdx.x * 1024 + threadIdx.x; idx < P * qn; idx += gridDim.x * 1024) {
+      const int p = idx / qn, q = idx % qn;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      const float* sp = j.src + (long)p * W_LDSLAB + q;
+      int i = 0;
+      for (; i + 3 < S; i += 4) {
+        s0 += sp[i * st]; s1 += sp[(i + 1) * st]; s2 += sp[(i + 2) * st]; s3 += sp[(i + 3) * st];
+      }
+      for (; i < S; ++i) s0 += sp[i * st];
+      const float s = (s0 + s1) + (s2 + s3);
+      if (q == Q) {
+        bias[p] = j.accumulate ? bias[p] + s : s;
+      } else {
+        const long o = j.trans ? (long)q * P + p : (long)p * Q + q;
+        grad[o] = j.accumulate ? grad[o] + s : s;
+      }
+    }
+    return;
+  }
+  // column partials: workgroup = 32 columns x 32 row groups of one segment
+  int k = 0, cb = blockIdx.x;
+  for (; k < 4; ++k) {
+    const int nb = j.out[k] ? (j.hi[k] - j.lo[k] + 31) / 32 : 0;
+    if (cb < nb) break;
+    cb -= nb;
+  }
+  if (k == 4) return;
+  const int lo = j.lo[k], n = j.hi[k] - lo, nblocks = j.S, width = j.P;
+  float* __restrict__ out = j.out[k];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = cb * 32 + c;
+  float s = 0.f;
+  if (i < n) {
+    const float* p = j.src + lo + i;
+    int b = rg;
+    for (; b + 96 < nblocks; b += 128) {
+      const float a0 = p[(long)b * width], a1 = p[(long)(b + 32) * width];
+      const float a2 = p[(long)(b + 64) * width], a3 = p[(long)(b + 96) * width];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < nblocks; b += 32) s += p[(long)b * width];
+  }
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && i < n) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r += 4) { t0 += red[r][c]; t1 += red[r + 1][c]; t2 += red[r + 2][c]; t3 += red[r + 3][c]; }
+    const float t = (t0 + t1) + (t2 + t3);
+    out[i] = j.accumulate ? out[i] + t : t;
+  }
+}
+
 // ---------------------------------------------------------------- host launchers
+hipError_t reduce_batch(const ReduceJob* jobs, int n, hipStream_t s) {
+  for (int at = 0; at < n; at += RB_MAX) {
+    const int m = n - at < RB_MAX ? n - at : RB_MAX;
+    ReduceJobs pack{};
+    int blocks = 1;
+    for (int i = 0; i < m; ++i) {
+      pack.job[i] = jobs[at + i];
+      const ReduceJob& j = pack.job[i];
+      int need = 0;
+      if (j.kind == 0) {
+        need = (j.P * (j.out[1] ? j.Q + 1 : j.Q) + 1023) / 1024;
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (j.out[k]) need += (j.hi[k] - j.lo[k] + 31) / 32;
+      }
+      if (need > blocks) blocks = need;
+    }
+    Traced tr(K_REDUCE_BATCH, 0, s);
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks, m), dim3(1024), 0, s, pack);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 static int row_grid(long T) {
   long waves = (T + 3) / 4;  // 4 waves per block
   return (int)(waves < 2048 ? (waves < 1 ? 1 : waves) : 2048);

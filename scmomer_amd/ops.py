@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import FavorPlan, FfnFwdArgs, View4, check, lib
+from ._lib import FavorPlan, FfnFwdArgs, ReduceJob, View4, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -105,12 +105,17 @@ def embed_fwd(tok: torch.Tensor, emb: torch.Tensor, g2v: Optional[torch.Tensor],
     return out
 
 
-def embed_bwd(tok: torch.Tensor, dx: torch.Tensor, num_tokens: int, grad: torch.Tensor, accumulate: bool):
+def embed_bwd(tok: torch.Tensor, dx: torch.Tensor, num_tokens: int, grad: torch.Tensor, accumulate: bool,
+              defer: Optional[list] = None):
+    """defer: a list that collects the final reduction as a job for reduce_batch instead of launching it here"""
     t = tok.numel()
     d = dx.shape[-1]
     ws = torch.empty(lib.scm_embed_bwd_ws_floats(t, d, num_tokens), dtype=F32, device=dx.device)
-    check(lib.scm_embed_bwd(_p(tok), _p(dx), t, d, num_tokens, _p(ws), _p(grad), int(accumulate), _stream()),
-          "scm_embed_bwd")
+    check(lib.scm_embed_bwd(_p(tok), _p(dx), t, d, num_tokens, _p(ws), None if defer is not None else _p(grad),
+                            int(accumulate), _stream()), "scm_embed_bwd")
+    if defer is not None:
+        width = num_tokens * d
+        defer.append(colsum_job(ws, ws.numel() // width, width, [(grad.view(-1), 0, width)], accumulate))
 
 
 # ----------------------------------------------------------------------------- layer norm
@@ -125,16 +130,22 @@ def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool, with_bf16: bool = False):
-    """-> dx f32, or (dx, dx rounded to bf16) when with_bf16"""
+def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool, with_bf16: bool = False,
+           defer: Optional[list] = None):
+    """-> dx f32, or (dx, dx rounded to bf16) when with_bf16.  defer: see embed_bwd."""
     _req(dy, F32, "dy")
     d = x.shape[-1]
     t = x.numel() // d
     dx = torch.empty_like(x)
     dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if with_bf16 else None
     ws = torch.empty(lib.scm_ln_bwd_ws_floats(t, d), dtype=F32, device=x.device)
+    now = defer is None
     check(lib.scm_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), t, d, _p(dx), _p(dxb), _p(ws),
-                         _p(dgamma), _p(dbeta), _p(dres_colsum), int(accumulate), _stream()), "scm_ln_bwd")
+                         _p(dgamma) if now else None, _p(dbeta) if now else None, _p(dres_colsum) if now else None,
+                         int(accumulate), _stream()), "scm_ln_bwd")
+    if not now:
+        defer.append(colsum_job(ws, ws.numel() // (3 * d), 3 * d,
+                                [(dgamma, 0, d), (dbeta, d, 2 * d), (dres_colsum, 2 * d, 3 * d)], accumulate))
     return (dx, dxb) if with_bf16 else dx
 
 
@@ -217,14 +228,42 @@ def wgrad_slices(t: int, p: int, q_bf16: bool = True) -> int:
     return max(1, min(tiles, 256 // ptiles))
 
 
-def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, trans: bool, accumulate: bool):
-    """grad (+)= pm^T qm  ([P,Q], or its transpose when trans); bias_grad (+)= column sums of pm."""
+def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, trans: bool, accumulate: bool,
+          defer: Optional[list] = None):
+    """grad (+)= pm^T qm  ([P,Q], or its transpose when trans); bias_grad (+)= column sums of pm.
+    defer: a list that collects the slab sum as a job for reduce_batch instead of launching it here."""
     t, p = pm.shape
     q = qm.shape[1]
     s = wgrad_slices(t, p, qm.dtype == BF16)
     ws = torch.empty(lib.scm_wgrad_ws_floats(p, s), dtype=F32, device=pm.device)
     check(lib.scm_wgrad(_p(pm), pm.stride(0), _p(qm), qm.stride(0), int(qm.dtype == F32), t, p, q, s, _p(ws),
-                        _p(grad), _p(bias_grad), int(trans), int(accumulate), _stream()), "scm_wgrad")
+                        None if defer is not None else _p(grad), _p(bias_grad), int(trans), int(accumulate), _stream()),
+          "scm_wgrad")
+    if defer is not None:
+        j = ReduceJob()
+        j.kind, j.accumulate, j.src, j.S, j.P, j.Q, j.trans = 0, int(accumulate), _p(ws), s, p, q, int(trans)
+        j.out[0], j.out[1] = _p(grad), _p(bias_grad)
+        defer.append((j, ws))
+
+
+def colsum_job(ws: torch.Tensor, rows: int, width: int, segs, accumulate: bool):
+    """reduce_batch job: out[i] (+)= sum over the `rows` partial rows of ws[:, lo + i] for every (out, lo, hi) of segs
+    whose out is not None"""
+    j = ReduceJob()
+    j.kind, j.accumulate, j.src, j.S, j.P = 1, int(accumulate), _p(ws), rows, width
+    for k, (out, lo, hi) in enumerate(segs):
+        j.out[k] = _p(out)
+        j.lo[k], j.hi[k] = lo, hi
+    return (j, ws)
+
+
+def reduce_batch(jobs: list):
+    """one launch for the collected reductions; the workspaces travel with the jobs and are released afterwards"""
+    if not jobs:
+        return
+    arr = (ReduceJob * len(jobs))(*[j for j, _ in jobs])
+    check(lib.scm_reduce_batch(arr, len(jobs), _stream()), "scm_reduce_batch")
+    jobs.clear()
 
 
 # ----------------------------------------------------------------------------- FAVOR+ attention
@@ -335,17 +374,25 @@ def head_fwd(x, gamma, beta, w, bias, relu: bool, want_enc: bool, want_out: bool
 
 
 def head_bwd(dout, denc, out, x, mean, rstd, gamma, beta, w, relu: bool, dgamma, dbeta, dw, db, accumulate: bool,
-             with_bf16: bool = False):
-    """-> dx f32, or (dx, dx rounded to bf16) when with_bf16"""
+             with_bf16: bool = False, defer: Optional[list] = None):
+    """-> dx f32, or (dx, dx rounded to bf16) when with_bf16.  defer: see embed_bwd."""
     d = x.shape[-1]
     t = x.numel() // d
     c = w.shape[0] if (w is not None and dout is not None) else 0
     dx = torch.empty_like(x)
     dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if with_bf16 else None
     ws = torch.empty(lib.scm_head_bwd_ws_floats(t, d, c), dtype=F32, device=x.device)
+    now = defer is None
     check(lib.scm_head_bwd(_p(dout), _p(denc), _p(out), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
-                           _p(w) if c else None, t, d, c, int(relu), _p(dx), _p(dxb), _p(ws), _p(dgamma), _p(dbeta),
-                           _p(dw) if c else None, _p(db) if c else None, int(accumulate), _stream()), "scm_head_bwd")
+                           _p(w) if c else None, t, d, c, int(relu), _p(dx), _p(dxb), _p(ws),
+                           _p(dgamma) if now else None, _p(dbeta) if now else None,
+                           _p(dw) if (c and now) else None, _p(db) if (c and now) else None, int(accumulate), _stream()),
+          "scm_head_bwd")
+    if not now:
+        width = 2 * d + c * d + c
+        defer.append(colsum_job(ws, ws.numel() // width, width,
+                                [(dgamma, 0, d), (dbeta, d, 2 * d), (dw.view(-1) if c else None, 2 * d, 2 * d + c * d),
+                                 (db if c else None, 2 * d + c * d, width)], accumulate))
     return (dx, dxb) if with_bf16 else dx
 
 

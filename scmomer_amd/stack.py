@@ -245,7 +245,8 @@ def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[tor
 
 
 def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
-             dres: Optional[torch.Tensor], need_dx: bool, dy_b: Optional[torch.Tensor] = None, want_b: bool = False):
+             dres: Optional[torch.Tensor], need_dx: bool, dy_b: Optional[torch.Tensor] = None, want_b: bool = False,
+             defer: Optional[list] = None):
     """dy: f32 [T,D] gradient of the branch output (dy_b: the same rounded to bf16, when the producer already
     wrote it; the matrix products read that copy).  Returns (dx f32 [T,D] or None, grads dict), dx being a
     (dx, dx_bf16) pair when want_b and ln.
@@ -258,7 +259,7 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
     g: Dict[str, torch.Tensor] = {}
     if need["wo"]:
         g["wo"] = torch.empty((d, inner), dtype=F32, device=dev)
-        ops.wgrad(tp.o.view(t, inner), dy if dy_b is None else dy_b, g["wo"], None, True, False)
+        ops.wgrad(tp.o.view(t, inner), dy if dy_b is None else dy_b, g["wo"], None, True, False, defer)
     need_qkv_w = need["wq"] or need["wk"] or need["wv"] or need["bq"]
     need_dh = need_dx or (ln and (need["g1"] or need["b1"]))
     if need_qkv_w or need_dh:
@@ -272,7 +273,7 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
         if need_qkv_w:
             gw = torch.empty((3 * inner, d), dtype=F32, device=dev)
             gb = torch.empty(3 * inner, dtype=F32, device=dev) if w["bqkv"] is not None else None
-            ops.wgrad(dqkv2, tp.h, gw, gb, False, False)
+            ops.wgrad(dqkv2, tp.h, gw, gb, False, False, defer)
             g["wq"], g["wk"], g["wv"] = gw[:inner], gw[inner:2 * inner], gw[2 * inner:]
             if gb is not None:
                 g["bq"], g["bk"], g["bv"] = gb[:inner], gb[inner:2 * inner], gb[2 * inner:]
@@ -284,7 +285,7 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
             g["g1"] = torch.empty(d, dtype=F32, device=dev)
             g["b1"] = torch.empty(d, dtype=F32, device=dev)
             g["bo"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
-            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g1"], dres, g["g1"], g["b1"], g["bo"], False, want_b)
+            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g1"], dres, g["g1"], g["b1"], g["bo"], False, want_b, defer)
         else:
             dx = dh
     if need["bo"] and g.get("bo") is None:
@@ -324,7 +325,8 @@ def ffn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torc
 
 
 def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
-            dres: Optional[torch.Tensor], need_dx: bool, dy_b: Optional[torch.Tensor] = None, want_b: bool = False):
+            dres: Optional[torch.Tensor], need_dx: bool, dy_b: Optional[torch.Tensor] = None, want_b: bool = False,
+            defer: Optional[list] = None):
     """as attn_bwd, for the FeedForward branch"""
     b, n, d = tp.shape
     t = b * n
@@ -333,7 +335,7 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
     g: Dict[str, torch.Tensor] = {}
     if need["w2"]:
         g["w2"] = torch.empty((d, f), dtype=F32, device=dev)
-        ops.wgrad(tp.act, dy if dy_b is None else dy_b, g["w2"], None, True, False)
+        ops.wgrad(tp.act, dy if dy_b is None else dy_b, g["w2"], None, True, False, defer)
     need_dh = need_dx or (ln and (need["g2"] or need["b2"]))
     if need["w1"] or need["c1"] or need_dh:
         dpre = ops.empty_rows(t, f, BF16, dev)
@@ -341,7 +343,7 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
         if need["w1"] or need["c1"]:
             g["w1"] = torch.empty((f, d), dtype=F32, device=dev)
             g["c1"] = torch.empty(f, dtype=F32, device=dev)
-            ops.wgrad(dpre, tp.h, g["w1"], g["c1"], False, False)
+            ops.wgrad(dpre, tp.h, g["w1"], g["c1"], False, False, defer)
     dx = None
     if need_dh:
         dh = torch.empty((t, d), dtype=F32, device=dev)
@@ -350,7 +352,7 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
             g["g2"] = torch.empty(d, dtype=F32, device=dev)
             g["b2"] = torch.empty(d, dtype=F32, device=dev)
             g["c2"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
-            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g2"], dres, g["g2"], g["b2"], g["c2"], False, want_b)
+            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g2"], dres, g["g2"], g["b2"], g["c2"], False, want_b, defer)
         else:
             dx = dh
     if need["c2"] and g.get("c2") is None:
@@ -456,6 +458,9 @@ class _StackFn(torch.autograd.Function):
         if need_inp:
             first = 0
         dout = dout.contiguous()
+        # The small reductions that end the gradient kernels (slab sums of the weight gradients, column sums of the
+        # LayerNorm / head / embedding gradients: about forty per backward) are collected and run as ONE launch.
+        jobs: list = []
         if ctx.head is not None:
             x, mean, rstd, out = ctx.head
             t, d = x.numel() // x.shape[-1], x.shape[-1]
@@ -469,7 +474,7 @@ class _StackFn(torch.autograd.Function):
                               None if want_out else dout.to(F32).reshape(t, d),
                               out, x, mean, rstd, spec.norm_w, spec.norm_b, spec.head_w if want_out else None,
                               spec.head_relu, gg, gb, gw.view(-1, d) if want_out else None,
-                              gbias.view(-1) if want_out else None, False, True)
+                              gbias.view(-1) if want_out else None, False, True, jobs)
             dx, dxb = dx[0].reshape(t, d), dx[1].reshape(t, d)
             grads[(-2, "norm_w")], grads[(-2, "norm_b")] = gg, gb
             if want_out:
@@ -488,14 +493,15 @@ class _StackFn(torch.autograd.Function):
             # the LayerNorm-backward kernels also emit their result rounded to bf16: the operand of the next
             # data- and weight-gradient products
             dx1, gf = ffn_bwd(dx, ft, fp, fw, nf, ln=True, dres=dx, need_dx=(not lowest) or attn_needs_any,
-                              dy_b=dxb, want_b=True)
+                              dy_b=dxb, want_b=True, defer=jobs)
             for k, v in gf.items():
                 if v is not None:
                     grads[(li, k)] = v
             if dx1 is None:
                 break
             dx1, dx1b = dx1
-            dx0, ga = attn_bwd(dx1, at, ap, aw, na, ln=True, dres=dx1, need_dx=not lowest, dy_b=dx1b, want_b=True)
+            dx0, ga = attn_bwd(dx1, at, ap, aw, na, ln=True, dres=dx1, need_dx=not lowest, dy_b=dx1b, want_b=True,
+                               defer=jobs)
             for k, v in ga.items():
                 if v is not None:
                     grads[(li, k)] = v
@@ -505,10 +511,11 @@ class _StackFn(torch.autograd.Function):
             if ctx.tokens is not None:
                 if need_p.get((-1, "token_emb"), False):
                     ge = torch.empty_like(spec.token_emb)
-                    ops.embed_bwd(ctx.tokens.contiguous(), dx, spec.token_emb.shape[0], ge, False)
+                    ops.embed_bwd(ctx.tokens.contiguous(), dx, spec.token_emb.shape[0], ge, False, jobs)
                     grads[(-1, "token_emb")] = ge
             else:
                 d_inp = dx.view(ctx.tapes[0][0].shape) if nl else dx
+        ops.reduce_batch(jobs)
         out_grads = []
         for i, nm in enumerate(spec.names):
             gval = grads.get(nm) if needs[2 + i] else None
