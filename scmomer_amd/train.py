@@ -236,11 +236,12 @@ class S1Trainer:
         masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
         logits = self.model(masked)
         loss = self.loss_fn(logits, labels, self.pad_id) / self.grad_acc
-        loss.backward()
         if self.params:
-            torch._foreach_add_(self.accs, [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params])
-        for p in self.params:
-            p.grad = None                                    # the next backward stores, it does not add
+            # autograd.grad hands the gradients back without going through the parameters' AccumulateGrad nodes (which
+            # are tied to the stream they were created on: recording this step on a side stream would mix streams)
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            torch._foreach_add_(self.accs, [g if g is not None else torch.zeros_like(p)
+                                            for g, p in zip(grads, self.params)])
         return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
 
     def _optimizer_step(self):
