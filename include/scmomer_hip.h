@@ -176,7 +176,9 @@ int64_t scm_favor_ws_floats(const scm_favor_plan* plan /* host */);
  *   ctx_bf16 [B*H,288,64] bf16 (centred K'^T V), z [B*H,288] f32, sums [B*H,80] f32 (obar, sum z, key stabiliser),
  *   rowmax [B*H*N] f32, den [B*H*N] f32,
  *   kmax [kmax_chunks*B*H] f32 (partial maxima; their max is the key stabiliser of performer_pytorch.py:90),
- *   kmax_idx [kmax_chunks*B*H] i64 (where each partial maximum sits: (bh*N + n)*512 + feature). */
+ *   kmax_idx [kmax_chunks*B*H] i64 (where each partial maximum sits: (bh*N + n)*512 + feature).
+ * When no backward follows, out_centered.p and rowmax / den (both) may be NULL: they are then not written
+ * (a third less traffic in the output pass). */
 int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, const void* omega_b,
                   scm_view4 out, scm_view4 out_centered, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
                   int64_t* kmax_idx, float* ws, void* stream);

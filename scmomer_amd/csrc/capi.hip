@@ -303,9 +303,10 @@ int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
                   scm_view4 out, scm_view4 out_centered, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
                   int64_t* kmax_idx, float* ws, void* stream) {
   SCM_REQ(plan_ok(plan), "scm_favor_fwd: bad plan");
-  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(out) && view_ok(out_centered),
+  SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(out) && (!out_centered.p || view_ok(out_centered)),
           "scm_favor_fwd: bad tensor view (null/unaligned)");
-  SCM_REQ(omega_b && ctx_bf16 && z && sums && rowmax && den && kmax && kmax_idx && ws, "scm_favor_fwd: null pointer");
+  SCM_REQ(omega_b && ctx_bf16 && z && sums && kmax && kmax_idx && ws, "scm_favor_fwd: null pointer");
+  SCM_REQ((rowmax && den) || (!rowmax && !den), "scm_favor_fwd: rowmax and den go together");
   SCM_REQ(aligned16(omega_b) && aligned16(ctx_bf16), "scm_favor_fwd: unaligned pointer");
   hipStream_t s = (hipStream_t)stream;
   const int B = plan->B, H = plan->H, N = plan->N;

@@ -627,8 +627,9 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
   const brsrc ry = make_rsrc(yb_, (uint32_t)(((long)(a.N - 1) * a.y.sn + DH) * 2));
   const brsrc ry2 = make_rsrc(y2b_, (uint32_t)(((long)(a.N - 1) * a.y2.sn + DH) * 2));
   const brsrc ro0 = make_rsrc(a.out0.p + b * a.out0.sb + h * a.out0.sh, (uint32_t)(((long)(a.N - 1) * a.out0.sn + DH) * 2));
-  const bf16* o1b_ = (MODE != 1) ? a.out1.p + b * a.out1.sb + h * a.out1.sh : xb;
-  const brsrc ro1 = make_rsrc(o1b_, (MODE != 1) ? (uint32_t)(((long)(a.N - 1) * a.out1.sn + DH) * 2) : 0u);
+  const bool has_out1 = MODE != 1 && a.out1.p != nullptr;   // MODE 0: the centred output is the backward's tape only
+  const bf16* o1b_ = has_out1 ? a.out1.p + b * a.out1.sb + h * a.out1.sh : xb;
+  const brsrc ro1 = make_rsrc(o1b_, has_out1 ? (uint32_t)(((long)(a.N - 1) * a.out1.sn + DH) * 2) : 0u);
   const brsrc rden = make_rsrc(MODE == 1 ? a.den_in + srow : nullptr, MODE == 1 ? (uint32_t)a.N * 4 : 0u);
   const brsrc rstab = make_rsrc(MODE == 1 ? a.stab + srow : nullptr, MODE == 1 ? (uint32_t)a.N * 4 : 0u);
   auto fetch = [&](int n0, bf16x8 (&fx)[4], bf16x8 (&fy)[4], bf16x8 (&fy2)[4], float& den, float& rmx) {
@@ -708,10 +709,10 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
       stage_rows(stage, Y, inv, nullptr, 0.f);
       __builtin_amdgcn_wave_barrier();
-      store_rows(stage, ro1, a.out1.sn, nullptr, 0.f, n0, n_hi);
+      if (has_out1) store_rows(stage, ro1, a.out1.sn, nullptr, 0.f, n0, n_hi);
       store_rows(stage, ro0, a.out0.sn, nullptr, 0.f, n0, n_hi, nullptr, sm);
       __builtin_amdgcn_wave_barrier();
-      if (valid && l < 32) { a.rowmax_out[srow + n] = mx; a.den_out[srow + n] = den; }
+      if (a.rowmax_out && valid && l < 32) { a.rowmax_out[srow + n] = mx; a.den_out[srow + n] = den; }
     }
 
     if (MODE == 1) {
@@ -946,7 +947,7 @@ hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s)
             th * (mode == 2 ? 102144.0 : 68628.0), s,
             // bytes per (token, head): mode 0 q in, out + centred out, 2 row scalars; mode 1 q, dout, centred out in,
             // dq out, 3 row scalars; mode 2 k, v in, dk, dv out
-            th * (mode == 0 ? 392.0 : (mode == 1 ? 524.0 : 512.0)));
+            th * (mode == 0 ? (a.out1.p ? 392.0 : 256.0) : (mode == 1 ? 524.0 : 512.0)));
   if (mode == 0) hipLaunchKernelGGL((favor_apply_kernel<0>), grid, dim3(512), lds, s, a);
   else if (mode == 1) hipLaunchKernelGGL((favor_apply_kernel<1>), grid, dim3(512), lds, s, a);
   else hipLaunchKernelGGL((favor_apply_kernel<2>), grid, dim3(512), lds, s, a);

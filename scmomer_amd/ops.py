@@ -286,21 +286,23 @@ def make_plan(b: int, h: int, n: int) -> FavorPlan:
 
 
 def favor_fwd(q, k, v, omega_b, out, out_centered) -> FavorSaved:
-    """q,k,v,out,out_centered: bf16 [B,H,N,64] views (any b/h/n strides)."""
+    """q,k,v,out,out_centered: bf16 [B,H,N,64] views (any b/h/n strides).  out_centered=None: no backward will
+    follow; the centred output and the per-token statistics are not written."""
     b, h, n, _ = q.shape
     dev = q.device
     plan = make_plan(b, h, n)
     bh = b * h
+    tape = out_centered is not None
     ctx = torch.empty((bh, NB_FEATURES_PAD, DIM_HEAD), dtype=BF16, device=dev)
     z = torch.empty((bh, NB_FEATURES_PAD), dtype=F32, device=dev)
     sums = torch.empty((bh, 80), dtype=F32, device=dev)
-    rowmax = torch.empty(bh * n, dtype=F32, device=dev)
-    den = torch.empty(bh * n, dtype=F32, device=dev)
+    rowmax = torch.empty(bh * n, dtype=F32, device=dev) if tape else None
+    den = torch.empty(bh * n, dtype=F32, device=dev) if tape else None
     kmax = torch.empty(plan.kmax_chunks * bh, dtype=F32, device=dev)
     kidx = torch.empty(plan.kmax_chunks * bh, dtype=torch.int64, device=dev)
     ws = torch.empty(lib.scm_favor_ws_floats(C.byref(plan)), dtype=F32, device=dev)
-    check(lib.scm_favor_fwd(C.byref(plan), view4(q), view4(k), view4(v), _p(omega_b), view4(out), view4(out_centered),
-                            _p(ctx), _p(z),
+    check(lib.scm_favor_fwd(C.byref(plan), view4(q), view4(k), view4(v), _p(omega_b), view4(out),
+                            view4(out_centered) if tape else View4(None, 0, 0, 0), _p(ctx), _p(z),
                             _p(sums), _p(rowmax), _p(den), _p(kmax), _p(kidx), _p(ws), _stream()), "scm_favor_fwd")
     return FavorSaved(plan, ctx, z, sums, rowmax, den, kmax, kidx)
 

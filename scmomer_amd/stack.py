@@ -235,8 +235,8 @@ def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[tor
     qkv5 = qkv.view(b, n, 3, heads, ops.DIM_HEAD)
     q, k, v = _qkv_views(qkv5)
     o = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device)
-    oc = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device)
-    saved = ops.favor_fwd(q, k, v, w["omega_b"], o.permute(0, 2, 1, 3), oc.permute(0, 2, 1, 3))
+    oc = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device) if save else None
+    saved = ops.favor_fwd(q, k, v, w["omega_b"], o.permute(0, 2, 1, 3), oc.permute(0, 2, 1, 3) if save else None)
     y = torch.empty((t, d), dtype=F32, device=x.device)
     ops.gemm_nt(ops.EPI_F32_BIAS_RES, o.view(t, inner), w["wo"], out0=y, bias=p["bo"],
                 resid=resid.reshape(t, d) if resid is not None else None)

@@ -224,6 +224,17 @@ def test_favor_forward(ops, b, h, n, scale):
     assert abs(float(c["saved"].kmax.max()) - float(s_k.max())) < 1e-4 * max(1.0, abs(float(s_k.max())))
 
 
+def test_favor_forward_without_tape_writes_the_same_output(ops):
+    """out_centered=None (no backward will follow): the centred output and the per-token statistics are skipped, the
+    attention output is the same to the bit."""
+    c = _favor_case(ops, 2, 3, 300, 1.0, 33)
+    out2 = torch.zeros_like(c["out"].permute(0, 2, 1, 3).contiguous()).permute(0, 2, 1, 3)
+    saved = ops.favor_fwd(c["q"], c["k"], c["v"], c["omb"], out2, None)
+    torch.cuda.synchronize()
+    assert saved.rowmax is None and saved.den is None
+    assert torch.equal(out2, c["out"])
+
+
 @pytest.mark.parametrize("b,h,n,scale", [(2, 3, 300, 1.0), (1, 10, 131, 1.5), (3, 2, 1000, 0.5)])
 def test_favor_backward(ops, b, h, n, scale):
     c = _favor_case(ops, b, h, n, scale, 32)
