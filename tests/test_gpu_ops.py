@@ -267,3 +267,43 @@ def test_favor_backward(ops, b, h, n, scale):
         ref = max(float(want.norm()), nat)
         print(f"{name}: |err| {err:.3e} |want| {float(want.norm()):.3e} natural {nat:.3e} ratio {err / ref:.3e}")
         assert err <= 1e-2 * ref, name
+
+
+# --------------------------------------------------------------------------------------- deferred reductions
+def test_reduce_batch_equals_the_immediate_reductions(ops):
+    """scm_reduce_batch over collected jobs (weight-gradient slabs with and without a bias column, transposed output,
+    accumulation into an existing gradient, LayerNorm / embedding column partials) gives the bits of the immediate
+    reductions."""
+    g = torch.Generator().manual_seed(77)
+    t, d = 5000, 200
+    pm = (torch.randn(t, 640, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    pm2 = (torch.randn(t, 800, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    qm = (torch.randn(t, d, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    x = torch.randn(t, d, generator=g).to(DEV)
+    dy = (torch.randn(t, d, generator=g) * 0.1).to(DEV)
+    tok = torch.randint(0, 7, (t,), generator=g).to(DEV)
+    h, mean, rstd = ops.ln_fwd(x, torch.ones(d, device=DEV), torch.zeros(d, device=DEV))
+    gamma = torch.ones(d, device=DEV)
+
+    def run(defer):
+        out = {}
+        out["w_t"] = torch.full((d, 640), 0.5, device=DEV)            # accumulate into an existing gradient, transposed
+        ops.wgrad(pm, qm, out["w_t"], None, True, True, defer)
+        out["w"] = torch.empty((800, d), device=DEV)
+        out["b"] = torch.empty(800, device=DEV)
+        ops.wgrad(pm2, qm, out["w"], out["b"], False, False, defer)
+        out["g"], out["be"], out["c"] = (torch.empty(d, device=DEV) for _ in range(3))
+        out["dx"] = ops.ln_bwd(dy, x, mean, rstd, gamma, dy, out["g"], out["be"], out["c"], False, False, defer)
+        out["e"] = torch.empty((7, d), device=DEV)
+        ops.embed_bwd(tok, dy, 7, out["e"], False, defer)
+        return out
+
+    now = run(None)
+    jobs = []
+    later = run(jobs)
+    assert len(jobs) == 4
+    ops.reduce_batch(jobs)
+    torch.cuda.synchronize()
+    assert not jobs
+    for k in now:
+        assert torch.equal(now[k], later[k]), k
