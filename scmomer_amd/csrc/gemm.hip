@@ -39,7 +39,8 @@ SCM_DEV void epilogue_pair(float* stage, const f32x16& acc0, const f32x16& acc1,
   __builtin_amdgcn_wave_barrier();
   const int ch = l & 7;
   const int col = col0 + 8 * ch;
-  const bool col_ok = (two || ch < 4) && col < N;
+  constexpr bool FOLDED_OR_PLAIN = EPI == EPI_F32 || (EPI == EPI_F32_BIAS_RES && FOLDED);
+  const bool col_ok = FOLDED_OR_PLAIN ? true : (two || ch < 4) && col < N;
   float bias[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bias[j] = 0.f;
@@ -53,6 +54,15 @@ SCM_DEV void epilogue_pair(float* stage, const f32x16& acc0, const f32x16& acc1,
     const int rl = 8 * pass + (l >> 3);
     const long row = row0 + rl;
     if (!col_ok || row >= M) continue;
+    if (FOLDED_OR_PLAIN) {
+      // f32 output with nothing left to add: the lane takes columns 4ch..4ch+3 of each 32-column half, so the eight
+      // lanes of a row write 128 contiguous bytes per store instruction (16-byte pieces at a 32-byte stride made
+      // twice the write requests)
+      float* op = (float*)e.out0 + row * e.ldo0 + col0 + 4 * ch;
+      if (col0 + 4 * ch < N) *(f32x4*)op = *(const f32x4*)(stage + rl * G_SP + 4 * ch);
+      if (two && col0 + 32 + 4 * ch < N) *(f32x4*)(op + 32) = *(const f32x4*)(stage + rl * G_SP + 32 + 4 * ch);
+      continue;
+    }
     const f32x4 a0 = *(const f32x4*)(stage + rl * G_SP + 8 * ch);
     const f32x4 a1 = *(const f32x4*)(stage + rl * G_SP + 8 * ch + 4);
     float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -310,23 +320,58 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
 //    REGISTERS once and stay there; the workgroup walks its range of output columns 64 at a time,
 //    streaming the matching W rows through one 32 KB LDS panel;
 //  * the product is formed TRANSPOSED (W rows on the MFMA row index, tokens on the lane), and the W rows
-//    of a chunk are permuted inside the panel so that every lane ends up holding, for ITS token, 4 groups
-//    of 8 consecutive output columns: the epilogue (bias, GELU, GELU', bf16 conversion) runs on the
-//    accumulators in registers and stores 16 bytes per lane -- no LDS round trip for the output.
+//    of a chunk are permuted inside the panel so that every lane ends up holding, for ITS token, 32
+//    consecutive output columns: the epilogue (bias, GELU, GELU', bf16 conversion) runs on the accumulators
+//    in registers; the 16-byte pieces are then transposed inside each quad of lanes so that a quad stores 64
+//    contiguous bytes of one token per instruction -- no LDS round trip for the output.
 //  grid = (ceil(M/128), column splits).
 // ------------------------------------------------------------------------------------------
 constexpr int SK_KS = 13;                 // k-steps held in registers (K <= 208)
 constexpr int SK_WBYTES = 4 * 64 * 128;   // one W chunk: 4 k-blocks of [64 rows][64 k] bf16 images
+#ifndef SK_AHEAD_STEPS
+#define SK_AHEAD_STEPS 2
+#endif
+constexpr int SK_AHEAD = SK_AHEAD_STEPS;  // k-steps by which the panel reads lead the products
 
-// panel row of output column c (0..63) of a chunk: tile t = (c>>2)&1, MFMA row i = 8(c>>4) + 4((c>>3)&1) + (c&3).
-// Accumulator register r of tile t on lane-half h then holds column 16(r>>2) + 8h + 4t + (r&3).
-SCM_DEV int sk_panel_row(int c) { return 32 * ((c >> 2) & 1) + 8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3); }
+// panel row of output column c (0..63) of a chunk: tile t = (c>>2)&1, MFMA row i = 8((c>>3)&3) + 4(c>>5) + (c&3).
+// Accumulator register r of tile t on lane-half h then holds column 32h + 8(r>>2) + 4t + (r&3): a lane ends with
+// 32 consecutive columns (64 bytes of bf16) of its token, as four 16-byte pieces.
+SCM_DEV int sk_panel_row(int c) { return 32 * ((c >> 2) & 1) + 8 * ((c >> 3) & 3) + 4 * (c >> 5) + (c & 3); }
+// byte offset of 16-byte k-chunk `chunk` (0..7) of panel row `row` inside a [64][64] bf16 k-block image: the chunk
+// position is XORed with (row >> 1) & 7, which makes the 16-lane groups of ds_read_b128 (rows 0-3, 12-15, 20-27 /
+// 4-11, 16-19, 28-31) hit sixteen different 16-byte bank groups.
+SCM_DEV int sk_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// 4x4 transpose of 16-byte pieces inside each quad of lanes: on return v[j] of quad lane i holds what v[i] of quad
+// lane j held.  With lane = token and v[p] = piece p of the token's 64 bytes, store j then writes, per quad, the 64
+// CONTIGUOUS bytes of token (quad base + j): one 64-byte request instead of four 16-byte ones.  The write path
+// takes requests, not bytes: with 16-byte pieces the K=200 products were bound by it (QKV: 62 -> 53 us).
+SCM_DEV void quad_transpose(u32x4 (&v)[4], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {      // exchange across lane bit 0: registers p (even) and p+1
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[p][d], 0xB1, 0xF, 0xF, true);       // lane ^ 1
+      const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[p + 1][d], 0xB1, 0xF, 0xF, true);
+      v[p][d] = b0 ? n1 : v[p][d];
+      v[p + 1][d] = b0 ? v[p + 1][d] : n0;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {         // exchange across lane bit 1: registers p and p+2
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[p][d], 0x4E, 0xF, 0xF, true);       // lane ^ 2
+      const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[p + 2][d], 0x4E, 0xF, 0xF, true);
+      v[p][d] = b1 ? n2 : v[p][d];
+      v[p + 2][d] = b1 ? v[p + 2][d] : n0;
+    }
+  }
+}
 
 // Loads that the epilogue waits for must not be issued after stores: memory operations retire in issue order, so
 // such a load would wait for the stores of the previous item.  Hence the bias vector is copied to LDS once, and the
 // pre-activation rows of the GELU' epilogue are fetched one item ahead, before the current item's stores.
-// The W panel is double-buffered in LDS (two workgroups per CU; a third one was measured to add nothing): the next
-// item's chunk is written to the other buffer while this item is multiplied, one barrier per item.
+// The W panel is double-buffered in LDS (two workgroups per CU; a third one was measured to add nothing): the
+// chunk of item i+2 is copied global->LDS asynchronously into the buffer item i has just left, one barrier per item.
 template <bool A_F32, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const void* __restrict__ Ap, long lda,
                                                              const bf16* __restrict__ W, long ldw, int M, int N,
@@ -344,7 +389,6 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const void* __restr
 
   // every global access goes through a bounds-checked buffer resource: out-of-range lanes pass BUF_OOB
   const brsrc rA = make_rsrc(Ap, (uint32_t)(((long)(M - 1) * lda + K) * AE));
-  const brsrc rW = make_rsrc(W, (uint32_t)(((long)(N - 1) * ldw + K) * 2));
   const brsrc rO0 = make_rsrc(e.out0, (uint32_t)(((long)(M - 1) * e.ldo0 + N) * 2));
   const brsrc rO1 = make_rsrc(EPI == EPI_GELU_DUAL ? e.out1 : e.out0,
                               (uint32_t)(((long)(M - 1) * (EPI == EPI_GELU_DUAL ? e.ldo1 : e.ldo0) + N) * 2));
@@ -358,37 +402,31 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const void* __restr
     for (int i = tid; i < 16 * nchunks; i += 256) *(u32x4*)(bias_s + 4 * i) = buf_load16(rB, (uint32_t)i * 16);
   int roff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) roff[i] = img_off(l & 31, 16 * i + 8 * half);
+  for (int i = 0; i < 4; ++i) roff[i] = sk_off(l & 31, 2 * i + half);
 
-  // W staging: thread (wr = tid>>2, q = tid&3) moves 16-byte k-chunks q, q+4, .., q+24 of W row n0 + wr
-  const int kc = K >> 3;
-  const int wr = tid >> 2, q = tid & 3;
-  const int prow = sk_panel_row(wr);
-  const int wdst0 = img_off(prow, 8 * q), wdst1 = img_off(prow, 8 * (q + 4));
-  const uint32_t wsrc = (uint32_t)(wr * ldw + 8 * q) * 2;
-  u32x4 wst[7];
-  auto load_w = [&](int it) {   // items past the range read the rows from N on: zeros
-    const int n0 = it < it_hi ? 64 * (it % nchunks) : N;
-    const uint32_t base = n0 + wr < N ? wsrc + (uint32_t)(n0 * ldw) * 2 : BUF_OOB;
+  // W staging: asynchronous global->LDS copies, 32 of 1 KB per chunk, instruction 4 j + w by wave w.  A copy fills
+  // LDS linearly in lane order, so each lane fetches the 16 bytes that BELONG at its slot: slot (panel row pr,
+  // position cp) of k-block j>>1 holds k-chunk cp ^ swizzle(pr) of W row n0 + sk_panel_col(pr).  Rows from N on and
+  // k-chunks from K/8 on are requested out of range and arrive as zeros.
+  const u32x4 rWd = dma_rsrc(W, (uint32_t)(((long)(N - 1) * ldw + K) * 2));
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const uint32_t lds0 = lds_addr_of(smem);
+  const int colA = 32 * (l >> 5) + 8 * w + ((l >> 3) & 3);        // + 4 (j & 1): column of the chunk held by this slot
+  const int chw = (l & 7) ^ ((4 * w + (l >> 4)) & 7);             // k-chunk inside the k-block
+  const uint32_t wbase = (uint32_t)(colA * ldw + 8 * chw) * 2;
+  const bool k3ok = 192 + 8 * chw < K;
+  auto issue_w = [&](int it, int buf) {
+    if (it >= it_hi) return;
+    const int n0 = 64 * (it % nchunks);
+    const uint32_t vb = wbase + (uint32_t)(n0 * ldw) * 2;
+    const bool r0ok = n0 + colA < N, r1ok = n0 + colA + 4 < N;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) wst[j] = buf_load16(rW, base + 64 * j);        // k chunks q+4j <= 23 < kc
-    wst[6] = buf_load16(rW, (q + 24 < kc) ? base + 64 * 6 : BUF_OOB);
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = ((j & 1) ? r1ok : r0ok) && (j < 6 || k3ok);
+      dma16_to_lds(rWd, lds0 + buf * SK_WBYTES + 1024 * (4 * j + wu),
+                   ok ? vb + (uint32_t)((j & 1) * 4 * ldw) * 2 + (j >> 1) * 128 : BUF_OOB, 0);
+    }
   };
-  auto store_w = [&](char* Wd) {   // chunks >= kc carry zeros: the panel's k tail is cleared on every refill
-#pragma unroll
-    for (int j = 0; j < 7; ++j) *(u32x4*)(Wd + (j >> 1) * (64 * 128) + ((j & 1) ? wdst1 : wdst0)) = wst[j];
-  };
-  // k chunks 28..31 of the last k-block are never written by store_w: clear them once, in both buffers
-  *(u32x4*)(smem + 3 * (64 * 128) + img_off(wr, 8 * (4 + q))) = u32x4{0, 0, 0, 0};
-  *(u32x4*)(smem + SK_WBYTES + 3 * (64 * 128) + img_off(wr, 8 * (4 + q))) = u32x4{0, 0, 0, 0};
-
-  // Software pipeline over the items: while item i is multiplied from one LDS buffer, the W chunk of item i+1
-  // (in registers since the previous iteration) is written to the other buffer and the loads of item i+2's chunk
-  // are issued, all before the epilogue's stores.
-  load_w(it_lo);
-  store_w(smem);
-  __syncthreads();
-  load_w(it_lo + 1);
 
   // A fragments of a row tile: global -> registers (lane: row l&31, k = 16 ks + 8 half .. +7).  Issued right
   // after the last MFMA of the previous tile, so the latency hides behind that item's epilogue.
@@ -421,36 +459,60 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const void* __restr
     const long r = (long)tl * G_BM + 32 * w + (l & 31);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int col = 64 * cc + 8 * half + 16 * g;
+      const int col = 64 * cc + 32 * half + 8 * g;
       dst[g] = buf_load16(rP, (item < it_hi && r < M && col < N) ? ((uint32_t)(r * e.ldp) + (uint32_t)col) * 2 : BUF_OOB);
     }
   };
   if (EPI == EPI_DGELU) load_pre(it_lo, pv);
+  issue_w(it_lo, 0);
+  issue_w(it_lo + 1, 1);
+  // Everything issued so far is waited for HERE, once.  Left to the compiler, the wait for the first row tile's A
+  // fragments lands inside the loop (its entry from above and its back edge are merged conservatively) and every
+  // item would then wait for the previous item's output stores to complete before its third product.
+  wait_vmcnt<0>();
+  __syncthreads();
+  constexpr int NST = EPI == EPI_GELU_DUAL ? 8 : 4;   // output stores per item
+  bf16x8 wf[SK_AHEAD + 1][2];             // ring of panel fragments, indexed by k-step mod (SK_AHEAD + 1)
+  auto read_w = [&](const char* Wp, int ks) {
+    const char* blk = Wp + (ks >> 2) * (64 * 128);
+    wf[ks % (SK_AHEAD + 1)][0] = *(const bf16x8*)(blk + roff[ks & 3]);
+    wf[ks % (SK_AHEAD + 1)][1] = *(const bf16x8*)(blk + 4096 + roff[ks & 3]);
+  };
+#pragma unroll
+  for (int ks = 0; ks < SK_AHEAD; ++ks) read_w(smem, ks);
   for (int it = it_lo; it < it_hi; ++it) {
     const int tile = it / nchunks, c = it - tile * nchunks;
     const long orow = row;          // the epilogue below still belongs to this item's tile
     const char* Ws = smem + ((it - it_lo) & 1) * SK_WBYTES;
-    store_w(smem + ((it - it_lo + 1) & 1) * SK_WBYTES);   // its last readers passed the barrier of the previous item
-    load_w(it + 2);
     f32x16 acc0 = zero16(), acc1 = zero16();
+    // The panel fragments run SK_AHEAD k-steps ahead of the products in a register ring, so a product never waits
+    // for the LDS; the ring's first steps were read at the end of the previous item, behind its epilogue.
 #pragma unroll
-    for (int ks = 0; ks < SK_KS; ++ks) {   // 26 independent LDS reads feeding 26 MFMAs
-      const char* blk = Ws + (ks >> 2) * (64 * 128);
-      acc0 = mfma32(*(const bf16x8*)(blk + roff[ks & 3]), af[ks], acc0);
-      acc1 = mfma32(*(const bf16x8*)(blk + 4096 + roff[ks & 3]), af[ks], acc1);
+    for (int ks = 0; ks < SK_KS; ++ks) {
+      if (ks + SK_AHEAD < SK_KS) read_w(Ws, ks + SK_AHEAD);
+      acc0 = mfma32(wf[ks % (SK_AHEAD + 1)][0], af[ks], acc0);
+      acc1 = mfma32(wf[ks % (SK_AHEAD + 1)][1], af[ks], acc1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // The copies of the next item's chunk were issued one item ago, ahead of that item's NST output stores; memory
+    // operations complete in issue order, so "all but the last NST" means they have landed while the stores may
+    // still be in flight.
+    wait_vmcnt<NST>();
+    __syncthreads();                       // next item's chunk visible to all; this item's buffer is free
+#pragma unroll
+    for (int ks = 0; ks < SK_AHEAD; ++ks) read_w(smem + ((it - it_lo + 1) & 1) * SK_WBYTES, ks);
     if (c + 1 == nchunks && it + 1 < it_hi) load_a(tile + 1);
     // ---- epilogue on registers: lane = token `orow`, group g = columns col .. col+7; straight-line
-    const int colb = 64 * c + 8 * half;
-    uint32_t oo[4], bias_off[4];
+    const int colb = 64 * c + 32 * half;
+    uint32_t bias_off[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = colb + 16 * g;
-      oo[g] = (orow < M && col < N) ? (uint32_t)col : BUF_OOB;   // column part; row part added per tensor
-      bias_off[g] = (uint32_t)col * 4;
-    }
+    for (int g = 0; g < 4; ++g) bias_off[g] = (uint32_t)(colb + 8 * g) * 4;
+    // after the in-quad transpose, store j carries piece (l & 3) of token (orow & ~3) + j
+    const int scol = colb + 8 * (l & 3);
+    const long srow = orow & ~3l;
     u32x4 npv[4];
     if (EPI == EPI_DGELU) load_pre(it + 1, npv);   // ahead of this item's stores
+    issue_w(it + 2, (it - it_lo) & 1);             // last among the loads: only the stores below follow it
     u32x4 ov[4], gv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -478,20 +540,21 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const void* __restr
         gv[g] = as_u32x4(gl);
       }
     }
-    // the four 32-byte pieces of each output line are stored back to back, one tensor after the other
+    // each tensor's four stores back to back: the two 64-byte halves of a 128-byte line come from lanes l, l+32
+    quad_transpose(ov, l);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      buf_store16(rO0, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo0) + oo[g]) * 2, ov[g]);
+    for (int j = 0; j < 4; ++j)
+      buf_store16(rO0, (srow + j < M && scol < N) ? ((uint32_t)((srow + j) * e.ldo0) + (uint32_t)scol) * 2 : BUF_OOB, ov[j]);
     if (EPI == EPI_GELU_DUAL) {
+      quad_transpose(gv, l);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        buf_store16(rO1, oo[g] == BUF_OOB ? BUF_OOB : ((uint32_t)(orow * e.ldo1) + oo[g]) * 2, gv[g]);
+      for (int j = 0; j < 4; ++j)
+        buf_store16(rO1, (srow + j < M && scol < N) ? ((uint32_t)((srow + j) * e.ldo1) + (uint32_t)scol) * 2 : BUF_OOB, gv[j]);
     }
     if (EPI == EPI_DGELU) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) pv[g] = npv[g];
     }
-    __syncthreads();                       // next item's chunk visible; this item's buffer is free
   }
 }
 
@@ -648,7 +711,7 @@ __global__ __launch_bounds__(320) void wgrad_kernel(const bf16* __restrict__ Pm,
 // wgrad_dma: the same product for bf16 operands, fed by asynchronous global->LDS copies.
 //   workgroup = 4 waves (one per SIMD), 128 P columns x up to 224 Q columns, 64-token stages in a ring of 3:
 //   while stage i is multiplied, the copies of stages i+1 and i+2 are in flight (no staging registers, one
-//   barrier per stage).  P stage: [64][128] bf16, 256-byte rows, 64-byte units XOR-swizzled by (row & 3) so that
+//   barrier per stage, placed inside the stage's last k-step).  P stage: [64][128] bf16, 256-byte rows, 64-byte units XOR-swizzled by (row & 3) so that
 //   the transposing reads are conflict free; Q stage: [64][224] bf16 at a 448-byte pitch.
 // ------------------------------------------------------------------------------------------
 constexpr int WD_BP = 128;
@@ -730,29 +793,77 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
   const int a_off = frow * 256 + ((((acol >> 3) ^ ((frow & 3) << 2))) << 4) + (acol & 7) * 2;
   const int b_off = frow * W_QP + (16 * (g & 1) + 4 * (i16 & 3)) * 2;
 
+  // Fragment registers are double-buffered by k-step: while the seven products of one k-step run, the sixteen
+  // transposing reads of the next one are issued in the gaps between them (at most four per gap), so every read has
+  // several products' time to return and no product waits on the LDS.  The step that ends a stage carries the
+  // workgroup barrier: its own fragments are already in registers, so the stage's buffer is free for the copy of
+  // the stage three ahead, and the reads that follow the barrier fetch the first k-step of the next stage.
+  bf16x4 fa[2][2], fb[2][7][2];
+  auto rd = [&](int set, const char* pb, int s, int i) {   // read number i (0..15) of k-step s of the stage at pb
+    const char* qb = pb + WD_PBYTES;
+    if (i < 2) fa[set][i] = lds_tr_read(pb + a_off + s * 4096 + i * 1024);
+    else {
+      const int t = (i - 2) >> 1, h = (i - 2) & 1;
+      fb[set][t][h] = lds_tr_read(qb + b_off + s * (16 * W_QP) + t * 64 + h * 4 * W_QP);
+    }
+  };
+  auto mm = [&](int set, int t) {
+    const bf16x8 a = {fa[set][0][0], fa[set][0][1], fa[set][0][2], fa[set][0][3],
+                      fa[set][1][0], fa[set][1][1], fa[set][1][2], fa[set][1][3]};
+    const bf16x8 b = {fb[set][t][0][0], fb[set][t][0][1], fb[set][t][0][2], fb[set][t][0][3],
+                      fb[set][t][1][0], fb[set][t][1][1], fb[set][t][1][2], fb[set][t][1][3]};
+    acc[t] = mfma32(a, b, acc[t]);
+  };
+  auto wait_landed = [&](int later_live) {   // this wave's copies of a stage: all but the stages issued after it
+    if (later_live >= 2) wait_vmcnt<22>(); else if (later_live == 1) wait_vmcnt<11>(); else wait_vmcnt<0>();
+  };
+
   issue(tile_lo, 0);
   issue(tile_lo + 1, 1);
+  issue(tile_lo + 2, 2);
+  wait_landed(max(0, min(2, tile_hi - 1 - tile_lo)));
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) rd(0, smem, 0, i);
   int buf = 0;
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    // this wave's copies of `tile` have landed once at most one later stage (11 copies) is still in flight
-    if (tile + 1 < tile_hi) wait_vmcnt<11>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();          // everyone's copies landed; everyone is done reading stage tile-1
-    issue(tile + 2, buf == 0 ? 2 : buf - 1);
     const char* pb = smem + buf * WD_STAGE;
-    const char* qb = pb + WD_PBYTES;
+    const int nbuf = buf == 2 ? 0 : buf + 1;
+    const char* npb = smem + nbuf * WD_STAGE;
 #pragma unroll
-    for (int s = 0; s < W_BT / 16; ++s) {
-      const bf16x4 alo = lds_tr_read(pb + a_off + s * 4096), ahi = lds_tr_read(pb + a_off + s * 4096 + 1024);
-      const bf16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+    for (int s = 0; s < 3; ++s) {          // k-steps 0..2: reads of step s+1 between the products of step s
+      constexpr int first[6] = {0, 4, 7, 10, 13, 16};
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
-        const bf16x4 blo = lds_tr_read(qb + b_off + s * (16 * W_QP) + t * 64);
-        const bf16x4 bhi = lds_tr_read(qb + b_off + s * (16 * W_QP) + t * 64 + 4 * W_QP);
-        const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-        acc[t] = mfma32(a, b, acc[t]);
+        mm(s & 1, t);
+        if (t < 5) {
+#pragma unroll
+          for (int i = first[t]; i < first[t + 1]; ++i) rd((s + 1) & 1, pb, s + 1, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    buf = buf == 2 ? 0 : buf + 1;
+    // k-step 3 (set 1): two products, then the barrier and the copy of stage tile+3, then the rest with the reads
+    // of the next stage's first k-step (set 0)
+    mm(1, 0);
+    mm(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));   // lgkmcnt(0): this stage is in registers
+    wait_landed(tile + 2 < tile_hi ? 1 : 0);                                // my copies of stage tile+1
+    __builtin_amdgcn_s_barrier();
+    issue(tile + 3, buf);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      constexpr int first[6] = {0, 4, 7, 10, 13, 16};
+#pragma unroll
+      for (int t = 2; t < 7; ++t) {
+        mm(1, t);
+#pragma unroll
+        for (int i = first[t - 2]; i < first[t - 1]; ++i) rd(0, npb, 0, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    buf = nbuf;
   }
 
   float* out = slab + (long)slice * P * W_LDSLAB;

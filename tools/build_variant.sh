@@ -4,7 +4,7 @@
 NAME=$1; DEFS=$2
 cd "$(dirname "$0")/../scmomer_amd/csrc" && mkdir -p build_$NAME
 for f in gemm ffn_chain norm_embed favor favor_free s1_tail ingest capi; do
-  EXTRA=""; [ $f = favor ] && EXTRA="-fno-slp-vectorize"
+  EXTRA=""; [ $f = favor -o $f = gemm ] && EXTRA="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-inline-asm $EXTRA $DEFS -c $f.hip -o build_$NAME/$f.o &
 done
 wait
