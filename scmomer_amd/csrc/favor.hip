@@ -658,6 +658,11 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
   bf16x8 xf[4], yf[4], y2f[4];
   float den_c = 1.f, rmx_c = 0.f;
   fetch(n_lo + 32 * w, xf, yf, y2f, den_c, rmx_c);
+  // The first tile's fragments are waited for HERE.  Otherwise the wait sits at the top of the loop, where the
+  // compiler must cover both ways in: coming from above the fragment loads are the youngest operations (wait for
+  // everything), on the back edge they are followed by the previous tile's stores -- and the merged wait made every
+  // tile wait for the stores of the one before.
+  wait_vmcnt<0>();
   for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 256) {
     const int n = n0 + (l & 31);
     const bool valid = n < n_hi;
