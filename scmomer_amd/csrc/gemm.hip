@@ -759,18 +759,19 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
     qv[jj] = chunk < qchunks ? (uint32_t)(row * ldq + 8 * chunk) * 2 : BUF_OOB;   // padding chunks receive zeros
     qmask[jj] = !(ONES && chunk == qchunks);                                       // the ones column is kept
   }
-  auto issue = [&](int tile, int buf) {
+  // copy number i (0..10) of this wave for a stage: 0..3 fill the P image, 4..10 the Q image.  A copy instruction
+  // holds the wave's issue for 60-180 cycles, so the eleven copies of a stage are not issued in one burst: they are
+  // placed one by one in the gaps between the products (a burst after the barrier cost as much as the stage's
+  // products themselves).
+  auto issue_piece = [&](int tile, int buf, int i) {
+    if (tile >= tile_hi) return;          // past the slice: nothing is copied (the stage is not read either)
     const uint32_t pb = lds0 + buf * WD_STAGE, qb = pb + WD_PBYTES;
-    const bool live = tile < tile_hi;     // past the slice: nothing is copied (the stage is not read either)
-    const uint32_t sp = (uint32_t)((long)tile * W_BT * ldp * 2), sq = (uint32_t)((long)tile * W_BT * ldq * 2);
-    if (live) {
+    if (i < 4) dma16_to_lds(rP, pb + 1024 * (4 * wu + i), pv[i], (uint32_t)((long)tile * W_BT * ldp * 2));
+    else if (!ONES || qmask[i - 4]) dma16_to_lds(rQ, qb + 1024 * (7 * wu + i - 4), qv[i - 4], (uint32_t)((long)tile * W_BT * ldq * 2));
+  };
+  auto issue = [&](int tile, int buf, int i0, int i1) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) dma16_to_lds(rP, pb + 1024 * (4 * wu + jj), pv[jj], sp);
-#pragma unroll
-      for (int jj = 0; jj < 7; ++jj) {
-        if (!ONES || qmask[jj]) dma16_to_lds(rQ, qb + 1024 * (7 * wu + jj), qv[jj], sq);
-      }
-    }
+    for (int i = i0; i < i1; ++i) issue_piece(tile, buf, i);
   };
   if (ONES) {   // column Q of every stage = 1 (tokens past T multiply zero-filled P rows)
     for (int i = tid; i < WD_NSTAGE * W_BT; i += 256) {
@@ -814,21 +815,21 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
                       fb[set][t][1][0], fb[set][t][1][1], fb[set][t][1][2], fb[set][t][1][3]};
     acc[t] = mfma32(a, b, acc[t]);
   };
-  auto wait_landed = [&](int later_live) {   // this wave's copies of a stage: all but the stages issued after it
-    if (later_live >= 2) wait_vmcnt<22>(); else if (later_live == 1) wait_vmcnt<11>(); else wait_vmcnt<0>();
-  };
-
-  issue(tile_lo, 0);
-  issue(tile_lo + 1, 1);
-  issue(tile_lo + 2, 2);
-  wait_landed(max(0, min(2, tile_hi - 1 - tile_lo)));
+  // Issue order of the copies: stage 0, stage 1 and the first NEARLY pieces of stage 2 before the loop; then, per
+  // stage t, the remaining pieces of stage t+2 (k-steps 0..2) and, after the barrier, the first pieces of stage t+3.  Copies complete in issue order, so "stage t+1 has landed" is a counted wait that
+  // leaves the eleven copies issued after it in flight.
+  constexpr int NPC = 11, NEARLY = 5;     // copies per stage; those issued in the stage's last k-step, after the barrier
+  issue(tile_lo, 0, 0, NPC);
+  issue(tile_lo + 1, 1, 0, NPC);
+  issue(tile_lo + 2, 2, 0, NEARLY);
+  if (tile_lo + 2 < tile_hi) wait_vmcnt<NPC + NEARLY>(); else if (tile_lo + 1 < tile_hi) wait_vmcnt<NPC>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < 16; ++i) rd(0, smem, 0, i);
   int buf = 0;
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const char* pb = smem + buf * WD_STAGE;
-    const int nbuf = buf == 2 ? 0 : buf + 1;
+    const int nbuf = buf == 2 ? 0 : buf + 1, pbuf = buf == 0 ? 2 : buf - 1;
     const char* npb = smem + nbuf * WD_STAGE;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {          // k-steps 0..2: reads of step s+1 between the products of step s
@@ -840,19 +841,21 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
 #pragma unroll
           for (int i = first[t]; i < first[t + 1]; ++i) rd((s + 1) & 1, pb, s + 1, i);
         }
+        // the other six pieces of stage tile+2 (its buffer was left at the barrier of stage tile-1): two at the end
+        // of each k-step (of the placements tried, the one with the shortest launch)
+        if (t == 5) issue_piece(tile + 2, pbuf, NEARLY + 2 * s);
+        if (t == 6) issue_piece(tile + 2, pbuf, NEARLY + 2 * s + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // k-step 3 (set 1): two products, then the barrier and the copy of stage tile+3, then the rest with the reads
-    // of the next stage's first k-step (set 0)
+    // k-step 3 (set 1): two products, then the barrier, then the rest with the reads of the next stage's first
+    // k-step (set 0) and the first pieces of stage tile+3 (into the buffer this stage has just left)
     mm(1, 0);
     mm(1, 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));   // lgkmcnt(0): this stage is in registers
-    wait_landed(tile + 2 < tile_hi ? 1 : 0);                                // my copies of stage tile+1
+    if (tile + 2 < tile_hi) wait_vmcnt<NPC>(); else wait_vmcnt<0>();        // my copies of stage tile+1
     __builtin_amdgcn_s_barrier();
-    issue(tile + 3, buf);
-    __builtin_amdgcn_sched_barrier(0);
     {
       constexpr int first[6] = {0, 4, 7, 10, 13, 16};
 #pragma unroll
@@ -860,6 +863,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
         mm(1, t);
 #pragma unroll
         for (int i = first[t - 2]; i < first[t - 1]; ++i) rd(0, npb, 0, i);
+        issue_piece(tile + 3, buf, t - 2);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
