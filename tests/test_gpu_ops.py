@@ -49,7 +49,10 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # --------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("m,n,k", [(300, 200, 640), (257, 1920, 200), (130, 800, 200), (64, 640, 200),
-                                   (513, 200, 1920), (100, 96, 72)])
+                                   (513, 200, 1920), (100, 96, 72),
+                                   # the A-in-registers kernel at its other contraction length, a partial last column
+                                   # chunk and row counts that split quads of rows
+                                   (257, 640, 208), (190, 328, 208), (131, 264, 200)])
 @pytest.mark.parametrize("a_f32", [False, True])
 def test_gemm_nt_plain(ops, m, n, k, a_f32):
     a = rnd(m, k, seed=1)
