@@ -33,10 +33,9 @@ constexpr int FC_STAGE = FC_W1BYTES + FC_W2BYTES;   // 60 KB
 constexpr int FC_VEC = 208;                     // floats per small vector in LDS (gamma, beta, ...)
 constexpr int FC_MAXF = 2048;                   // hidden width bound (bias vector in LDS)
 
-// panel row (0..63) of column c (0..63) of a chunk or of a pair of output tiles, and its inverse:
-// tile t = (c>>2)&1, MFMA row i = 8(c>>4) + 4((c>>3)&1) + (c&3); register r of tile t on lane-half h then holds
-// column 16(r>>2) + 8h + 4t + (r&3), i.e. the lane has 8 consecutive columns per register group.
-SCM_DEV int fc_panel_row(int c) { return 32 * ((c >> 2) & 1) + 8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3); }
+// column (0..63) of a chunk, or of a pair of output tiles, that sits in panel row pr (0..63): tile t = pr>>5, MFMA
+// row i = pr&31 = 8m + 4h + n -> column 16m + 8h + 4t + n; register r = 4m + n of tile t on lane-half h then holds
+// that column, i.e. the lane has 8 consecutive columns per register group.
 SCM_DEV int fc_panel_col(int pr) {
   const int t = pr >> 5, i = pr & 31;
   return 16 * (i >> 3) + 8 * ((i >> 2) & 1) + 4 * t + (i & 3);

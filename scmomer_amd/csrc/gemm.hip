@@ -333,10 +333,10 @@ constexpr int SK_WBYTES = 4 * 64 * 128;   // one W chunk: 4 k-blocks of [64 rows
 #endif
 constexpr int SK_AHEAD = SK_AHEAD_STEPS;  // k-steps by which the panel reads lead the products
 
-// panel row of output column c (0..63) of a chunk: tile t = (c>>2)&1, MFMA row i = 8((c>>3)&3) + 4(c>>5) + (c&3).
-// Accumulator register r of tile t on lane-half h then holds column 32h + 8(r>>2) + 4t + (r&3): a lane ends with
-// 32 consecutive columns (64 bytes of bf16) of its token, as four 16-byte pieces.
-SCM_DEV int sk_panel_row(int c) { return 32 * ((c >> 2) & 1) + 8 * ((c >> 3) & 3) + 4 * (c >> 5) + (c & 3); }
+// Output column (0..63 inside a chunk) whose W row sits in panel row pr: tile t = pr>>5, MFMA row i = pr&31 with
+// i = 8m + 4h + n  ->  column 32h + 8m + 4t + n.  Accumulator register r = 4m + n of tile t on lane-half h then
+// holds that column: a lane ends with 32 consecutive columns (64 bytes of bf16) of its token, as four 16-byte pieces.
+SCM_DEV int sk_panel_col(int pr) { return 32 * ((pr >> 2) & 1) + 8 * ((pr >> 3) & 3) + 4 * (pr >> 5) + (pr & 3); }
 // byte offset of 16-byte k-chunk `chunk` (0..7) of panel row `row` inside a [64][64] bf16 k-block image: the chunk
 // position is XORed with (row >> 1) & 7, which makes the 16-lane groups of ds_read_b128 (rows 0-3, 12-15, 20-27 /
 // 4-11, 16-19, 28-31) hit sixteen different 16-byte bank groups.
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const void* __restr
   const u32x4 rWd = dma_rsrc(W, (uint32_t)(((long)(N - 1) * ldw + K) * 2));
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const uint32_t lds0 = lds_addr_of(smem);
-  const int colA = 32 * (l >> 5) + 8 * w + ((l >> 3) & 3);        // + 4 (j & 1): column of the chunk held by this slot
+  const int colA = sk_panel_col(8 * w + (l >> 3));                // panel rows 8w + (l>>3) (j even) and 32 + that (j odd: + 4)
   const int chw = (l & 7) ^ ((4 * w + (l >> 4)) & 7);             // k-chunk inside the k-block
   const uint32_t wbase = (uint32_t)(colA * ldw + 8 * chw) * 2;
   const bool k3ok = 192 + 8 * chw < K;
