@@ -253,10 +253,16 @@ __global__ __launch_bounds__(256) void s1_accuracy_kernel(const float* __restric
 hipError_t s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, long long pad_id, float* ratio,
                        int* counts, int* arrivals, hipStream_t s) {
   Traced tr(K_CE, 0, s);
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * 2 * sizeof(int), s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(arrivals, 0, (size_t)B * sizeof(int), s);
-  if (e != hipSuccess) return e;
+  hipError_t e;
+  if (arrivals == counts + 2 * B) {        // one workspace (the usual case): one clear
+    e = hipMemsetAsync(counts, 0, (size_t)B * 3 * sizeof(int), s);
+    if (e != hipSuccess) return e;
+  } else {
+    e = hipMemsetAsync(counts, 0, (size_t)B * 2 * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(arrivals, 0, (size_t)B * sizeof(int), s);
+    if (e != hipSuccess) return e;
+  }
   const int chunks = (N + 255) / 256 < 64 ? (N + 255) / 256 : 64;
   hipLaunchKernelGGL(s1_accuracy_kernel, dim3(chunks, B), dim3(256), 0, s, logits, labels, N, C, pad_id, ratio, counts,
                      arrivals);

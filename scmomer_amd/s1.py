@@ -23,7 +23,10 @@ def data_mask_device(data: torch.Tensor, mask_prob: float, replace_prob: float, 
     if rand_pick is None:
         rand_pick = torch.rand(data.shape, device=data.device)
     if rand_replace is None:
-        rand_replace = torch.zeros_like(data).float().uniform_(0, 1)
+        # the reference draws into torch.zeros_like(data).float() (s1_pretrain_rna.py:118): uniform_ overwrites every
+        # element from the generator alone, so an uninitialised f32 buffer gives the same draws without the fill
+        # and the conversion kernels
+        rand_replace = torch.empty(data.shape, dtype=torch.float32, device=data.device).uniform_(0, 1)
     return ops.s1_mask(data.contiguous(), rand_pick.contiguous(), rand_replace.contiguous(), mask_prob, replace_prob,
                        pad_token_id, mask_token_id)
 

@@ -227,6 +227,7 @@ class S1Trainer:
         if performer is not None and self.world > 1:
             performer.redraw_sync = lambda perf: sdist.broadcast_projections(perf, src=0, group=group)
         self.index = 0                                       # micro-steps since the start of the epoch
+        self._seed = None                                    # 1/grad_acc on the device: the backward's seed
         self.use_graph = use_graph
         self._graph = None
         self._graph_shape = None
@@ -235,11 +236,16 @@ class S1Trainer:
     def _forward_backward(self, data: torch.Tensor):
         masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
         logits = self.model(masked)
-        loss = self.loss_fn(logits, labels, self.pad_id) / self.grad_acc
+        raw = self.loss_fn(logits, labels, self.pad_id)
+        loss = raw / self.grad_acc
         if self.params:
             # autograd.grad hands the gradients back without going through the parameters' AccumulateGrad nodes (which
-            # are tied to the stream they were created on: recording this step on a side stream would mix streams)
-            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            # are tied to the stream they were created on: recording this step on a side stream would mix streams).
+            # The backward starts from the unscaled loss with 1/grad_acc as its seed: the value the division's own
+            # backward would pass on (1.0 * 1/grad_acc), without its two small kernels.
+            if self._seed is None or self._seed.device != raw.device:
+                self._seed = torch.full((), 1.0, dtype=raw.dtype, device=raw.device) / self.grad_acc
+            grads = torch.autograd.grad(raw, self.params, grad_outputs=self._seed, allow_unused=True)
             torch._foreach_add_(self.accs, [g if g is not None else torch.zeros_like(p)
                                             for g, p in zip(grads, self.params)])
         return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
