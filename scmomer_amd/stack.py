@@ -394,6 +394,75 @@ def _flat_params(spec: StackSpec) -> List[torch.Tensor]:
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# gradient sink: parameter gradients written straight into a caller's accumulators
+# --------------------------------------------------------------------------------------------
+_SINK: Optional[Dict[int, torch.Tensor]] = None     # id(parameter) -> f32 accumulator of the parameter's shape
+
+
+class grad_sink:
+    """Context manager for a training driver that accumulates gradients over micro-steps: inside it, a backward
+    pass of the fused stack ADDS every parameter gradient whose final reduction it can redirect into accs[i] (the
+    last launch of the backward does the add) and hands None back to autograd for that parameter, instead of
+    materialising the gradient for the caller to add.  Gradients it cannot redirect are returned as usual.  The
+    backward runs on autograd's device thread, so the table is process-wide, not thread-local: one driver at a time."""
+
+    def __init__(self, params, accs):
+        self.table = {id(p): a for p, a in zip(params, accs)}
+
+    def __enter__(self):
+        global _SINK
+        _SINK = self.table
+        return self
+
+    def __exit__(self, *exc):
+        global _SINK
+        _SINK = None
+        return False
+
+
+def _redirect_jobs(jobs: list, grads: Dict[Tuple[int, str], torch.Tensor], byname: Dict[Tuple[int, str], Any]) -> set:
+    """Point the deferred reductions at the sink's accumulators where that is exact: every output of a job must be
+    covered by gradient tensors whose accumulators sit at the same relative offsets (the fused q/k/v weight gradient
+    is one [3*inner, D] output: its three accumulators must be adjacent).  Returns the names now accumulated in place."""
+    sunk: set = set()
+    if not _SINK:
+        return sunk
+    spans = []                                       # (gradient pointer, bytes, name, accumulator)
+    for nm, gt in grads.items():
+        acc = _SINK.get(id(byname.get(nm)))
+        spans.append((gt.data_ptr(), gt.numel() * 4, nm, acc if (acc is not None and gt.is_contiguous() and
+                                                                 acc.is_contiguous() and acc.dtype == F32 and
+                                                                 acc.numel() == gt.numel()) else None))
+    for j, _ws in jobs:
+        if j.kind == 0:
+            outs = [(0, j.P * j.Q * 4)] + ([(1, j.P * 4)] if j.out[1] else [])
+        else:
+            outs = [(k, (j.hi[k] - j.lo[k]) * 4) for k in range(4) if j.out[k]]
+        plan, names, ok = [], [], True
+        for k, nbytes in outs:
+            o = j.out[k]
+            members = [sp for sp in spans if o <= sp[0] < o + nbytes]
+            base = next((sp for sp in members if sp[0] == o), None)
+            if base is None or base[3] is None or sum(sp[1] for sp in members) != nbytes:
+                ok = False
+                break
+            for sp in members:
+                if sp[3] is None or sp[3].data_ptr() - base[3].data_ptr() != sp[0] - o:
+                    ok = False
+                    break
+            if not ok:
+                break
+            plan.append((k, base[3].data_ptr()))
+            names += [sp[2] for sp in members]
+        if ok and plan:
+            for k, ptr in plan:
+                j.out[k] = ptr
+            j.accumulate = 1
+            sunk.update(names)
+    return sunk
+
+
 class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec: StackSpec, inp: torch.Tensor, *params):
@@ -515,10 +584,11 @@ class _StackFn(torch.autograd.Function):
                     grads[(-1, "token_emb")] = ge
             else:
                 d_inp = dx.view(ctx.tapes[0][0].shape) if nl else dx
+        sunk = _redirect_jobs(jobs, grads, dict(zip(spec.names, _flat_params(spec)))) if _SINK else set()
         ops.reduce_batch(jobs)
         out_grads = []
         for i, nm in enumerate(spec.names):
-            gval = grads.get(nm) if needs[2 + i] else None
+            gval = grads.get(nm) if (needs[2 + i] and nm not in sunk) else None
             out_grads.append(gval)
         ctx.tapes = None
         return (None, d_inp, *out_grads)

@@ -245,9 +245,14 @@ class S1Trainer:
             # backward would pass on (1.0 * 1/grad_acc), without its two small kernels.
             if self._seed is None or self._seed.device != raw.device:
                 self._seed = torch.full((), 1.0, dtype=raw.dtype, device=raw.device) / self.grad_acc
-            grads = torch.autograd.grad(raw, self.params, grad_outputs=self._seed, allow_unused=True)
-            torch._foreach_add_(self.accs, [g if g is not None else torch.zeros_like(p)
-                                            for g, p in zip(grads, self.params)])
+            # the encoder's backward adds its gradients into the accumulators itself (its last launch, the batched
+            # reductions, does the add); what it hands back are the gradients of anything outside the fused stack
+            from . import stack
+            with stack.grad_sink(self.params, self.accs):
+                grads = torch.autograd.grad(raw, self.params, grad_outputs=self._seed, allow_unused=True)
+            left = [(a, g) for a, g in zip(self.accs, grads) if g is not None]
+            if left:
+                torch._foreach_add_([a for a, _ in left], [g for _, g in left])
         return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
 
     def _optimizer_step(self):
