@@ -274,7 +274,8 @@ def run_s3(args, world, rank, device):
     s3.freeze_for_distillation(model)
     model.rna_model.model.fix_projection_matrices_()
     model = model.to(device).train()
-    stepper = s3.S3Step(model, lr=1e-4, grad_acc=args.grad_acc, pos_weight=1.0, distill_weight=1.0)
+    stepper = s3.S3Step(model, lr=1e-4, grad_acc=args.grad_acc, pos_weight=1.0, distill_weight=1.0,
+                        use_graph=not args.eager)
     gen = torch.Generator().manual_seed(100 + rank)
     data = []
     for _ in range(2):
@@ -307,7 +308,7 @@ def run_s3(args, world, rank, device):
                                    "MSE + distillation loss; backward; clip + Adam every grad_acc steps",
                        "cells_per_gpu_per_step": batch, "gene_tokens": N_GENES, "atac_peaks": n_peaks, "depth": 6,
                        "dim": 200, "heads": 10, "nb_features": 266, "grad_acc": args.grad_acc,
-                       "parallelism": f"dp{world}", "launch": "eager"},
+                       "parallelism": f"dp{world}", "launch": "eager" if args.eager else "graph replay"},
             "final_losses": {k: float(v.item()) for k, v in losses.items()},
             "redraw_counter": int(model.rna_model.model.performer.calls_since_last_redraw),
             "roofline": {"whole_step_frac_of_mfma_peak": value / world * 307.52e9 / 1e12 / PEAK_BF16_TFLOPS},

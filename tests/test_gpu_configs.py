@@ -138,3 +138,33 @@ def test_s3_distillation_step_vs_oracle(S):
     for k, v in before.items():
         moved = not torch.equal(after[k].detach(), v)
         assert moved == k.startswith(("encoder.", "to_out.", "RNA.", "ATAC.")), k
+
+
+def test_s3_step_graph_replay_equals_eager(S):
+    """The recorded S3 micro-step (use_graph=True) gives the losses and the updated weights of the eager one over two
+    optimizer steps of two micro-steps each, and ticks the frozen encoder's redraw counter once per micro-step."""
+    from scmomer_amd import s3
+    n_peaks, bsz = 3000, 3
+    p = O.make_scmomer_params(6)
+    rng = np.random.default_rng(70)
+    t = lambda *s_, sc=0.05: torch.from_numpy((rng.standard_normal(s_) * sc).astype(np.float32))
+    dec = {"RNA.output_mean.0.weight": t(N, 128), "RNA.output_mean.0.bias": t(N),
+           "ATAC.output_mean.0.weight": t(n_peaks, 128), "ATAC.output_mean.0.bias": t(n_peaks)}
+    batches = [(torch.from_numpy(O.synthetic_cells(71 + i, bsz, N)).to(DEV),
+                torch.from_numpy((rng.random((bsz, n_peaks)) < 0.05).astype(np.float32)).to(DEV),
+                t(bsz, 128, sc=1.0).to(DEV)) for i in range(4)]
+    results = []
+    for use_graph in (False, True):
+        m = _scmomer(S, {**p, **dec}, rna_decoder=s3.ReconstructNet(N, 128), atac_decoder=s3.ReconstructNet(n_peaks, 128))
+        s3.freeze_for_distillation(m)
+        m.train()
+        m.rna_model.model.performer.fix_projection_matrices_()
+        step = s3.S3Step(m, lr=1e-3, grad_acc=2, pos_weight=2.0, distill_weight=0.5, use_graph=use_graph)
+        losses = [float(step.micro_step(*b)["total"]) for b in batches]
+        results.append((losses, {k: v.detach().clone() for k, v in m.named_parameters()},
+                        int(m.rna_model.model.performer.calls_since_last_redraw)))
+    (l0, w0, c0), (l1, w1, c1) = results
+    assert l0 == l1, (l0, l1)
+    assert c0 == c1 == len(batches)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
