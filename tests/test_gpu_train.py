@@ -230,3 +230,43 @@ def test_two_optimizer_steps_vs_oracle_autograd_and_adam(mods):
                 worst_l2 = (k, l2)
             assert cos >= 0.99 and l2 <= 0.13, f"{k}: update cosine {cos:.4f}, rel L2 {l2:.3f}"
         print(f"graph={use_graph}: weight updates vs oracle Adam: worst cosine {worst_cos}, worst rel L2 {worst_l2}")
+
+
+def test_gradient_sink_adds_what_autograd_would_return(mods):
+    """Inside stack.grad_sink the backward adds every parameter gradient straight into the driver's accumulators
+    (the slices of one flat bucket, as in S1Trainer) and returns None for it; the accumulators end up with the bits
+    of 'materialise the gradients, then add them'."""
+    ingest, s1, train = mods
+    from scmomer_amd import dist as sdist
+    from scmomer_amd import stack
+    n, b = 517, 3
+    m = _model(n)
+    m.train()
+    params = [p for p in m.parameters() if p.requires_grad]
+    tok = torch.from_numpy(np.minimum(_cells(3, b, n), 5).astype(np.int64)).to(DEV)
+    gen = torch.Generator().manual_seed(11)
+    pick, rep = torch.rand((b, n), generator=gen).to(DEV), torch.rand((b, n), generator=gen).to(DEV)
+
+    def run(sink):
+        bucket = sdist.GradientAverager(params)
+        accs = list(bucket.views)
+        for a in accs:
+            a.fill_(0.125)
+        masked, labels = s1.data_mask_device(tok, 0.15, 0.9, 6, 6, rand_pick=pick, rand_replace=rep)
+        loss = s1.masked_cross_entropy(m(masked), labels, 6)
+        if sink:
+            with stack.grad_sink(params, accs):
+                grads = torch.autograd.grad(loss, params, allow_unused=True)
+        else:
+            grads = torch.autograd.grad(loss, params, allow_unused=True)
+        returned = sum(g is not None for g in grads)
+        for a, g in zip(accs, grads):
+            if g is not None:
+                a.add_(g)
+        return bucket.flat.clone(), returned
+
+    plain, n_plain = run(False)
+    sunk, n_sunk = run(True)
+    assert n_plain == len(params)
+    assert n_sunk == 0, f"{n_sunk} gradients were still materialised"
+    assert torch.equal(plain, sunk)
