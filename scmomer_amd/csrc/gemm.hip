@@ -218,14 +218,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const void* __restrict__ A
 // gemm_nt_dma: Y[M, N<=224] = A[M,K] * W[N,K]^T for bf16 A, fed by asynchronous global->LDS copies.
 //   The rows are dealt out EVENLY: workgroup b owns rows [M b/G, M (b+1)/G), at most 224 of them (7 waves x 32
 //   rows x 7 accumulators), with G a multiple of the CU count, so one round of workgroups keeps every CU equally
-//   busy on this bandwidth-bound product.  64-wide k stages alternate between two LDS buffers: while stage i is
-//   multiplied, the copies of stage i+1 are in flight (no staging registers, one barrier per stage).  The LDS
+//   busy on this bandwidth-bound product.  64-wide k stages go through LDS rings (A: three stages, W: two): while
+//   stage i is multiplied, the A copies of stages i+1 and i+2 are in flight (no staging registers, one barrier per
+//   stage); what a CU has in flight bounds the rate at which its rows stream in from HBM.  The LDS
 //   images are the swizzled 128-byte-row images of gemm_nt (each lane of a copy fetches the 16-byte chunk that
 //   belongs at its linear LDS position).  Epilogue: the LDS-staged coalesced one above.
 // ------------------------------------------------------------------------------------------
 constexpr int GD_NT = 7;                       // accumulator tiles per wave (N <= 224)
 constexpr int GD_ROWS = 224;                   // rows per workgroup (7 waves)
-constexpr int GD_STAGE = (GD_ROWS + GD_NT * 32) * 128;   // 56 KB
+constexpr int GD_ABYTES = GD_ROWS * 128;       // one A stage: [224 rows][64 k] bf16, 28 KB
+constexpr int GD_WBYTES = GD_NT * 32 * 128;    // one W stage: [224 columns][64 k] bf16, 28 KB
+constexpr int GD_NA = 3, GD_NW = 2;            // ring depths: A streams from HBM (two stages ahead), W sits in L2
+constexpr int GD_LDS = GD_NA * GD_ABYTES + GD_NW * GD_WBYTES;   // 140 KB
 
 template <int EPI>
 __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict__ A, long lda,
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
   const u32x4 rA = dma_rsrc(A, (uint32_t)(((long)(M - 1) * lda + K) * 2));
   const u32x4 rW = dma_rsrc(W, (uint32_t)(((long)(N - 1) * ldw + K) * 2));
   const uint32_t lds0 = lds_addr_of(smem);
+  char* const wring = smem + GD_NA * GD_ABYTES;
 
   // per-lane source offsets (k-tile 0); a copy covers 8 image rows: lane -> row 8j + (l>>3), linear chunk l&7,
   // which holds source chunk (l&7) ^ swizzle(row)
@@ -252,17 +257,32 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
     av[jj] = (r0 + row < r1) ? (uint32_t)((r0 + row) * lda + 8 * c) * 2 : BUF_OOB;
     wv[jj] = (row < N) ? (uint32_t)((long)row * ldw + 8 * c) * 2 : BUF_OOB;
   }
-  auto issue = [&](int kt, int buf) {
+  // four 1 KB copies per wave and stage, for A and for W; chunks past K arrive as zeros
+  auto issue_a = [&](int kt) {
     if (kt >= nk) return;
-    const uint32_t ab = lds0 + buf * GD_STAGE, wb = ab + GD_ROWS * 128;
-    const uint32_t so = (uint32_t)kt * (G_BK * 2);
+    const uint32_t ab = lds0 + (kt % GD_NA) * GD_ABYTES, so = (uint32_t)kt * (G_BK * 2);
     const int kleft = (K - kt * G_BK) >> 3;     // valid 16-byte chunks of this k-tile (>= 8 except in the tail)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const bool ok = kc[jj] < kleft;
-      dma16_to_lds(rA, ab + 1024 * (4 * wu + jj), ok ? av[jj] : BUF_OOB, so);
-      dma16_to_lds(rW, wb + 1024 * (4 * wu + jj), ok ? wv[jj] : BUF_OOB, so);
-    }
+    for (int jj = 0; jj < 4; ++jj) dma16_to_lds(rA, ab + 1024 * (4 * wu + jj), kc[jj] < kleft ? av[jj] : BUF_OOB, so);
+  };
+  auto piece_a = [&](int kt, int jj) {
+    if (kt >= nk) return;
+    const uint32_t ab = lds0 + (kt % GD_NA) * GD_ABYTES, so = (uint32_t)kt * (G_BK * 2);
+    const int kleft = (K - kt * G_BK) >> 3;
+    dma16_to_lds(rA, ab + 1024 * (4 * wu + jj), kc[jj] < kleft ? av[jj] : BUF_OOB, so);
+  };
+  auto piece_w = [&](int kt, int jj) {
+    if (kt >= nk) return;
+    const uint32_t wb = lds0 + GD_NA * GD_ABYTES + (kt % GD_NW) * GD_WBYTES, so = (uint32_t)kt * (G_BK * 2);
+    const int kleft = (K - kt * G_BK) >> 3;
+    dma16_to_lds(rW, wb + 1024 * (4 * wu + jj), kc[jj] < kleft ? wv[jj] : BUF_OOB, so);
+  };
+  auto issue_w = [&](int kt) {
+    if (kt >= nk) return;
+    const uint32_t wb = lds0 + GD_NA * GD_ABYTES + (kt % GD_NW) * GD_WBYTES, so = (uint32_t)kt * (G_BK * 2);
+    const int kleft = (K - kt * G_BK) >> 3;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dma16_to_lds(rW, wb + 1024 * (4 * wu + jj), kc[jj] < kleft ? wv[jj] : BUF_OOB, so);
   };
 
   f32x16 acc[GD_NT];
@@ -272,7 +292,8 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) roff[i] = img_off(l & 31, 16 * i + 8 * (l >> 5));
 
-  issue(0, 0);
+  // issue order: A0 W0 A1 W1 | A2 W2 | A3 W3 | ...  (copies complete in issue order)
+  issue_a(0); issue_w(0); issue_a(1); issue_w(1);
   if (EPI == EPI_F32_BIAS_RES) {
     // Y = A W^T + bias + residual: the accumulators START at bias + residual (lane = column, registers = rows; a
     // load instruction covers two rows x 128 contiguous bytes), fetched while the first k stages are in flight.
@@ -291,18 +312,62 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
         acc[t][r] = bv + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, (int)off, 0, 0));
       }
     }
+    wait_vmcnt<0>();                         // (the initial values come after the copies in issue order)
+  } else {
+    if (nk > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();   // stage 0 has landed
   }
+  __builtin_amdgcn_s_barrier();
+
+  // Fragment registers are double-buffered by k-step: the eight LDS reads of the next k-step are issued in the gaps
+  // between the seven products of this one, so no product waits for the LDS.  The last k-step of a stage carries the
+  // workgroup barrier: its fragments are already in registers, so both buffers of the stage are free for the copies
+  // of later stages, and the reads that follow fetch the next stage's first k-step.  The copies are not issued in a
+  // burst (a copy instruction holds the wave's issue for 60-180 cycles) but one per gap between products: the four W
+  // copies of stage kt+2 right after the barrier, the four A copies of stage kt+2 at the ends of k-steps 0 and 1.
+  // Either measure alone (deeper ring, or spreading with one stage of prefetch) gained nothing; together -12 % at
+  // K = 1920.
+  bf16x8 fa[2], fw[2][GD_NT];
+  auto rd = [&](int set, const char* Aw, const char* Ws, int s2, int i) {   // read i (0..7) of k-step s2
+    if (i == 0) fa[set] = *(const bf16x8*)(Aw + roff[s2]);
+    else fw[set][i - 1] = *(const bf16x8*)(Ws + 4096 * (i - 1) + roff[s2]);
+  };
+  {
+    const char* Aw = smem + 4096 * w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rd(0, Aw, wring, 0, i);
+  }
+  constexpr int first[6] = {0, 2, 4, 6, 7, 8};   // reads issued after product t: [first[t], first[t+1])
   for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt<0>();                       // this wave's copies of stage kt have landed
-    __builtin_amdgcn_s_barrier();          // everyone's have; everyone is done reading the other buffer
-    issue(kt + 1, (kt + 1) & 1);
-    const char* Aw = smem + (kt & 1) * GD_STAGE + 4096 * w;
-    const char* Ws = smem + (kt & 1) * GD_STAGE + GD_ROWS * 128;
+    const char* Aw = smem + (kt % GD_NA) * GD_ABYTES + 4096 * w;
+    const char* Ws = wring + (kt % GD_NW) * GD_WBYTES;
+    const char* nAw = smem + ((kt + 1) % GD_NA) * GD_ABYTES + 4096 * w;
+    const char* nWs = wring + ((kt + 1) % GD_NW) * GD_WBYTES;
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const bf16x8 a = *(const bf16x8*)(Aw + roff[s2]);
+    for (int s2 = 0; s2 < 3; ++s2) {
 #pragma unroll
-      for (int t = 0; t < GD_NT; ++t) acc[t] = mfma32(a, *(const bf16x8*)(Ws + 4096 * t + roff[s2]), acc[t]);
+      for (int t = 0; t < GD_NT; ++t) {
+        acc[t] = mfma32(fa[s2 & 1], fw[s2 & 1][t], acc[t]);
+        if (t < 5) {
+#pragma unroll
+          for (int i = first[t]; i < first[t + 1]; ++i) rd((s2 + 1) & 1, Aw, Ws, s2 + 1, i);
+        }
+        if (s2 < 2 && (t == 5 || t == 6)) piece_a(kt + 2, 2 * s2 + (t - 5));   // A two stages ahead: one per gap
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    acc[0] = mfma32(fa[1], fw[1][0], acc[0]);
+    acc[1] = mfma32(fa[1], fw[1][1], acc[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));   // lgkmcnt(0): this stage is in registers
+    if (kt + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();                 // stage kt+1 landed (A(kt+2) may fly)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 2; t < GD_NT; ++t) {
+      acc[t] = mfma32(fa[1], fw[1][t], acc[t]);
+#pragma unroll
+      for (int i = first[t - 2]; i < first[t - 1]; ++i) rd(0, nAw, nWs, 0, i);
+      if (t < 6) piece_w(kt + 2, t - 2);     // W two stages ahead, into the buffer this stage has just left
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();                          // all reads of the buffers are done: reuse them as the epilogue stage
@@ -1005,7 +1070,7 @@ static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, 
     return launch_skinny<A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
   if (!A_F32 && N <= 224 && K >= 128 && (long)M * lda * 2 < lim && (long)N * ldw * 2 < lim &&
       (EPI != EPI_F32_BIAS_RES || !e.resid || (long)M * e.ldr * 4 < lim)) {
-    const size_t lds = (size_t)2 * GD_STAGE;
+    const size_t lds = (size_t)GD_LDS;
     static std::atomic<unsigned long long> ready;
     if (hipError_t e = ensure_dynamic_lds((const void*)gemm_nt_dma_kernel<EPI>, lds, ready); e != hipSuccess) return e;
     // whole rounds of 256 workgroups with at most 224 rows each; small problems: one workgroup per 32 rows
