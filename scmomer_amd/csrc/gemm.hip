@@ -884,6 +884,10 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
   // stage t, the remaining pieces of stage t+2 (k-steps 0..2) and, after the barrier, the first pieces of stage t+3.  Copies complete in issue order, so "stage t+1 has landed" is a counted wait that
   // leaves the eleven copies issued after it in flight.
   constexpr int NPC = 11, NEARLY = 5;     // copies per stage; those issued in the stage's last k-step, after the barrier
+#ifdef SCM_STAMPS   // diagnostic build only (tools/wgrad_stamps.py): shader-clock and 100 MHz stamps around the phases,
+                    // written BEHIND the slabs, so the workspace must be 64 bytes per wave larger than the product needs
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   issue(tile_lo, 0, 0, NPC);
   issue(tile_lo + 1, 1, 0, NPC);
   issue(tile_lo + 2, 2, 0, NEARLY);
@@ -892,6 +896,9 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) rd(0, smem, 0, i);
   int buf = 0;
+#ifdef SCM_STAMPS
+  const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const char* pb = smem + buf * WD_STAGE;
     const int nbuf = buf == 2 ? 0 : buf + 1, pbuf = buf == 0 ? 2 : buf - 1;
@@ -935,6 +942,9 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
     buf = nbuf;
   }
 
+#ifdef SCM_STAMPS
+  const unsigned long long st2 = __builtin_amdgcn_s_memtime(), sr2 = __builtin_amdgcn_s_memrealtime();
+#endif
   float* out = slab + (long)slice * P * W_LDSLAB;
   const int qlim = ONES ? Q + 1 : Q;
 #pragma unroll
@@ -947,6 +957,14 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
       if (p < P) out[(long)p * W_LDSLAB + col] = acc[t][r];
     }
   }
+#ifdef SCM_STAMPS
+  wait_vmcnt<0>();
+  const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+  if (l == 0) {
+    unsigned long long* dbg = (unsigned long long*)(slab + (long)(gridDim.x / ptiles) * P * W_LDSLAB) + ((long)blockIdx.x * 4 + w) * 8;
+    dbg[0] = st1 - st0; dbg[1] = st2 - st1; dbg[2] = st3 - st2; dbg[3] = sr2 - sr1; dbg[4] = tile_hi - tile_lo; dbg[5] = sr0; dbg[6] = sr2;
+  }
+#endif
 }
 
 // grad (+)= sum_s slab[s][p][q];  trans: grad is [Q,P] (grad[q*P+p]) else [P,Q].
