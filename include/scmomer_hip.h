@@ -105,6 +105,21 @@ enum { SCM_EPI_BF16 = 0, SCM_EPI_F32_BIAS_RES = 1, SCM_EPI_GELU_DUAL = 2, SCM_EP
 int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W_bf16, int64_t ldw, int M, int N, int K,
                 void* out0, int64_t ldo0, void* out1, int64_t ldo1, const float* bias, const float* resid,
                 int64_t ldr, const void* pre_bf16, int64_t ldp, void* stream);
+/* ---- the data-gradient product that ends a sublayer's backward, with the LayerNorm backward as its epilogue:
+ *      dx = dres + dLN(A W^T) for the PreLayerNorm of performer_pytorch.py:289-295 wrapped around the to_q/to_k/to_v
+ *      (:374-376) or FeedForward.w1 (:323) Linear.  It replaces scm_gemm_nt(SCM_EPI_F32) followed by scm_ln_bwd: the
+ *      f32 product rows stay on the chip.  A [M,K] bf16, W [D,K] bf16; x, dres, dx: [M,D] f32, contiguous rows;
+ *      other arguments as scm_ln_bwd (dgamma, dbeta, dres_colsum may all be NULL: then the column partials are left
+ *      in ws, [scm_gemm_ln_bwd_ws_floats(M,D) / (3 D)][3 D], for a later scm_reduce_batch).
+ *      Sizes: scm_gemm_ln_bwd_supported (D <= 224, D % 4 == 0, K >= 128, K % 8 == 0, M D < 2^28); other sizes are
+ *      rejected with SCM_EINVAL and take the two separate calls. */
+int scm_gemm_ln_bwd_supported(int64_t M, int D, int K, int64_t lda, int64_t ldw);
+int64_t scm_gemm_ln_bwd_ws_floats(int64_t M, int D);
+int scm_gemm_ln_bwd(const void* A_bf16, int64_t lda, const void* W_bf16, int64_t ldw, int64_t M, int D, int K,
+                    const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                    float* dx, void* dx_bf16, float* ws, float* dgamma, float* dbeta, float* dres_colsum,
+                    int accumulate, void* stream);
+
 /* ---- forward of the FeedForward sublayer in one launch: PreLayerNorm(Chunk(FeedForward)),
  *      performer_pytorch.py:289-331, with the residual add of reversible.py:145.  Model dim D = 200 and a hidden
  *      width F % 8 == 0, F <= 2048 (scm_ffn_chain_supported); other sizes use scm_ln_fwd + scm_gemm_nt.

@@ -55,6 +55,9 @@ SIGNATURES = {
     "scm_ln_fwd": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp]),
     "scm_ln_bwd_ws_floats": (i64, [i64, i32]),
     "scm_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "scm_gemm_ln_bwd_supported": (i32, [i64, i32, i32, i64, i64]),
+    "scm_gemm_ln_bwd_ws_floats": (i64, [i64, i32]),
+    "scm_gemm_ln_bwd": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "scm_ln_bwd_noalloc": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp]),
     "scm_gemm_nt": (i32, [i32, i32, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp]),
     "scm_reduce_batch": (i32, [C.POINTER(ReduceJob), i32, vp]),

@@ -49,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -173,6 +173,34 @@ int scm_ln_bwd_noalloc(const float* dy, const float* x, const float* mean, const
   SCM_HIP(ln_bwd_static_scratch(&ws), "scm_ln_bwd_noalloc(scratch address)");
   return scm_ln_bwd(dy, x, mean, rstd, gamma, dres, T, D, dx, dx_bf16, ws, dgamma, dbeta, dres_colsum, accumulate,
                     stream);
+}
+
+int scm_gemm_ln_bwd_supported(int64_t M, int D, int K, int64_t lda, int64_t ldw) {
+  return (M > 0 && M < (1ll << 31) && D > 0 && K > 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K &&
+          gemm_ln_bwd_supported((long)M, D, K, (long)lda, (long)ldw)) ? 1 : 0;
+}
+int64_t scm_gemm_ln_bwd_ws_floats(int64_t M, int D) { return (int64_t)gemm_ln_bwd_blocks((long)M) * 3 * D; }
+
+int scm_gemm_ln_bwd(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int D, int K, const float* x,
+                    const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                    void* dx_bf16, float* ws, float* dgamma, float* dbeta, float* dres_colsum, int accumulate,
+                    void* stream) {
+  SCM_REQ(A && W && x && mean && rstd && gamma && dx && ws, "scm_gemm_ln_bwd: null pointer");
+  SCM_REQ(scm_gemm_ln_bwd_supported(M, D, K, lda, ldw),
+          "scm_gemm_ln_bwd: unsupported sizes (M=%lld D=%d K=%d): use scm_gemm_nt + scm_ln_bwd", (long long)M, D, K);
+  SCM_REQ(aligned16(A) && aligned16(W) && aligned16(x) && aligned16(gamma) && aligned16(dx) &&
+              (!dres || aligned16(dres)) && (!dx_bf16 || aligned16(dx_bf16)),
+          "scm_gemm_ln_bwd: unaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  GemmEpi e{};
+  e.out0 = dx; e.ldo0 = D; e.resid = dres; e.ldr = D;
+  e.ln_x = x; e.ln_mean = mean; e.ln_rstd = rstd; e.ln_gamma = gamma; e.ln_dxb = (bf16*)dx_bf16; e.ln_partial = ws;
+  SCM_HIP(gemm_ln_bwd(A, lda, W, ldw, (int)M, D, K, e, s), "scm_gemm_ln_bwd");
+  if (dgamma || dbeta || dres_colsum) {
+    const ColsumSegs seg{{dgamma, dbeta, dres_colsum, nullptr}, {0, D, 2 * D, 0}, {D, 2 * D, 3 * D, 0}};
+    SCM_HIP(colsum_reduce(ws, gemm_ln_bwd_blocks((long)M), 3 * D, seg, 3, accumulate, s), "scm_gemm_ln_bwd(column sums)");
+  }
+  return 0;
 }
 
 int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,

@@ -17,6 +17,7 @@ namespace scm {
 // gemm_nt
 // ------------------------------------------------------------------------------------------
 enum { EPI_BF16 = 0, EPI_F32_BIAS_RES = 1, EPI_GELU_DUAL = 2, EPI_DGELU = 3, EPI_F32 = 4, EPI_BF16_BIAS = 5 };
+constexpr int EPI_LN_BWD = 6;   // internal: LayerNorm backward on the product's rows (gemm_ln_bwd), not an scm_gemm_nt epilogue
 
 constexpr int G_BM = 128;
 constexpr int G_BK = 64;
@@ -231,6 +232,137 @@ constexpr int GD_WBYTES = GD_NT * 32 * 128;    // one W stage: [224 columns][64 
 constexpr int GD_NA = 3, GD_NW = 2;            // ring depths: A streams from HBM (two stages ahead), W sits in L2
 constexpr int GD_LDS = GD_NA * GD_ABYTES + GD_NW * GD_WBYTES;   // 140 KB
 
+// LayerNorm backward as the epilogue of the N <= 224 product: dx = dres + LN'(dh) with dh = the accumulators, never
+// written to memory.  Each wave stages its 32 rows, 16 at a time, as f32 rows in LDS and then walks them one row per
+// trip with the lane = 4 columns shape of ln_bwd_kernel (same arithmetic, same column partials).  The x / dres rows
+// come in batches of four, two batches in flight: a batch is requested before the previous one's stores are issued
+// (memory operations retire in issue order).  Rows past r1 and columns past N are out of range of the buffer
+// resources: they load zeros and their stores are dropped.
+constexpr int LNB_PITCH = 232;                 // floats per staged row; 4 * 232 mod 64 = 32: the lane halves (rows 4 apart) use disjoint banks
+constexpr int LNB_STAGE = 16 * LNB_PITCH;      // floats per wave
+constexpr int LNB_LDS = 7 * LNB_STAGE * 4 + 7 * 3 * 256 * 4;   // stages + cross-wave column sums: 122.5 KB
+
+SCM_DEV void ln_bwd_epilogue(char* smem, f32x16 (&acc)[7], long r0, long r1, int M, int N, const GemmEpi& e) {
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  float* stage = (float*)smem + w * LNB_STAGE;
+  const bool active = 4 * l < N;
+  const int lcol = active ? 4 * l : 0;                     // inactive lanes read column 0 and contribute nothing
+  const uint32_t lane_off = active ? 16u * l : BUF_OOB;    // byte offset inside a row; out of range for inactive lanes
+  const int base = (int)r0 + 32 * w, rend = (int)r1;
+  const uint32_t bytes4 = (uint32_t)((long)M * N * 4);     // < 1 GiB (gemm_ln_bwd_supported)
+  const brsrc rX = make_rsrc(e.ln_x, bytes4);
+  const brsrc rR = make_rsrc(e.resid ? (const void*)e.resid : (const void*)e.ln_x, e.resid ? bytes4 : 0u);
+  const brsrc rDx = make_rsrc(e.out0, bytes4);
+  const brsrc rDb = make_rsrc(e.ln_dxb ? (void*)e.ln_dxb : e.out0, e.ln_dxb ? bytes4 / 2 : 0u);
+  const brsrc rMu = make_rsrc(e.ln_mean, (uint32_t)M * 4), rRs = make_rsrc(e.ln_rstd, (uint32_t)M * 4);
+  const brsrc rG = make_rsrc(e.ln_gamma, (uint32_t)N * 4);
+  const f32x4 g = as_f32x4(buf_load16(rG, lane_off));
+  const float invN = 1.f / (float)N;
+
+  f32x4 xv[2][4], rv[2][4];
+  float mu4[2], rs4[2];
+  // byte offset of this lane's piece of row base + 4 b + j; rows past the workgroup's range get an offset past 1 GiB
+  auto row_off = [&](int b, int j) -> uint32_t {
+    const int row = base + 4 * b + j;                      // wave-uniform
+    return (row < rend ? (uint32_t)row * (uint32_t)(N * 4) : 0x40000000u) + lane_off;
+  };
+  auto load_batch = [&](int b, int set) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t off = row_off(b, j);
+      xv[set][j] = as_f32x4(buf_load16(rX, off));
+      rv[set][j] = as_f32x4(buf_load16(rR, off));
+    }
+    const int srow = base + 4 * b + (l & 3);
+    const int soff = srow < rend ? srow * 4 : (int)BUF_OOB;
+    mu4[set] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMu, soff, 0, 0));
+    rs4[set] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rRs, soff, 0, 0));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto stage_pass = [&](int p) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int col = 32 * t + (l & 31);     // all 224 columns are staged (the pitch holds them); those past N are not read
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) stage[(acc_row(8 * p + rr, half) - 16 * p) * LNB_PITCH + col] = acc[t][8 * p + rr];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x4 ag = f32x4{0, 0, 0, 0}, ab = ag, ar = ag;
+  // one batch: the four rows side by side, so that the eight wave sums overlap (gamma is zero in the inactive lanes,
+  // which therefore add nothing to the sums; what they accumulate in ag/ab/ar is never read)
+  auto process = [&](int b, int set) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp += 2) {
+      f32x4 d[2], xh[2];
+      float s1[2], s2[2], rsv[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j = jp + q;
+        d[q] = *(const f32x4*)(stage + (4 * (b & 3) + j) * LNB_PITCH + lcol);
+        const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mu4[set]), j));
+        rsv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs4[set]), j));
+        s1[q] = 0.f; s2[q] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xh[q][i] = (xv[set][j][i] - mu) * rsv[q];
+          const float gd = d[q][i] * g[i];
+          s1[q] += gd;
+          s2[q] += gd * xh[q][i];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        s1[q] = wave_sum_uniform(s1[q]) * invN;
+        s2[q] = wave_sum_uniform(s2[q]) * invN;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j = jp + q;
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] = rv[set][j][i] + rsv[q] * (d[q][i] * g[i] - s1[q] - xh[q][i] * s2[q]);
+          ag[i] += d[q][i] * xh[q][i];
+          ab[i] += d[q][i];
+          ar[i] += rv[set][j][i];
+        }
+        const uint32_t off = row_off(b, j);
+        buf_store16(rDx, off, __builtin_bit_cast(u32x4, o));
+        const bf16x4 ob = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rDb, (int)(off >> 1), 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  load_batch(0, 0);
+  stage_pass(0);
+  load_batch(1, 1);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    process(b, b & 1);
+    if (b == 3) stage_pass(1);            // rows 16..31; the reads of rows 0..15 precede it in the wave's LDS order
+    if (b + 2 < 8) load_batch(b + 2, b & 1);
+  }
+  // column partials of the workgroup: seven waves summed in wave order
+  float* red = (float*)smem + 7 * LNB_STAGE;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    red[(w * 3 + 0) * 256 + 4 * l + i] = ag[i];
+    red[(w * 3 + 1) * 256 + 4 * l + i] = ab[i];
+    red[(w * 3 + 2) * 256 + 4 * l + i] = ar[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * N; i += 448) {
+    const int k = i / N, dd = i - k * N;
+    float sum = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 7; ++ww) sum += red[(ww * 3 + k) * 256 + dd];
+    e.ln_partial[(long)blockIdx.x * 3 * N + i] = sum;
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict__ A, long lda,
                                                           const bf16* __restrict__ W, long ldw, int M, int N, int K,
@@ -371,12 +503,16 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
     }
   }
   __syncthreads();                          // all reads of the buffers are done: reuse them as the epilogue stage
-  float* stage = (float*)smem + w * (32 * G_SP);
-  const int mlim = (int)r1;                 // rows from r1 on belong to the next workgroup
+  if constexpr (EPI == EPI_LN_BWD) {
+    ln_bwd_epilogue(smem, acc, r0, r1, M, N, e);
+  } else {
+    float* stage = (float*)smem + w * (32 * G_SP);
+    const int mlim = (int)r1;               // rows from r1 on belong to the next workgroup
 #pragma unroll
-  for (int tp = 0; tp < (GD_NT + 1) / 2; ++tp)
-    epilogue_pair<EPI, EPI == EPI_F32_BIAS_RES>(stage, acc[2 * tp], acc[(2 * tp + 1 < GD_NT) ? 2 * tp + 1 : 2 * tp],
-                                                2 * tp + 1 < GD_NT, r0 + 32 * w, 64 * tp, mlim, N, e);
+    for (int tp = 0; tp < (GD_NT + 1) / 2; ++tp)
+      epilogue_pair<EPI, EPI == EPI_F32_BIAS_RES>(stage, acc[2 * tp], acc[(2 * tp + 1 < GD_NT) ? 2 * tp + 1 : 2 * tp],
+                                                  2 * tp + 1 < GD_NT, r0 + 32 * w, 64 * tp, mlim, N, e);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1075,6 +1211,13 @@ static hipError_t launch_skinny(const void* A, long lda, const bf16* W, long ldw
   return hipGetLastError();
 }
 
+static long nt_dma_grid(long M) {
+  // whole rounds of 256 workgroups with at most 224 rows each; small problems: one workgroup per 32 rows
+  long grid = 256 * ((M + 256l * GD_ROWS - 1) / (256l * GD_ROWS));
+  if (grid > (M + 31) / 32) grid = (M + 31) / 32;
+  return grid;
+}
+
 template <bool A_F32, int EPI>
 static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, int M, int N, int K, GemmEpi e,
                               hipStream_t s) {
@@ -1091,9 +1234,7 @@ static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, 
     const size_t lds = (size_t)GD_LDS;
     static std::atomic<unsigned long long> ready;
     if (hipError_t e = ensure_dynamic_lds((const void*)gemm_nt_dma_kernel<EPI>, lds, ready); e != hipSuccess) return e;
-    // whole rounds of 256 workgroups with at most 224 rows each; small problems: one workgroup per 32 rows
-    long grid = 256 * (((long)M + 256l * GD_ROWS - 1) / (256l * GD_ROWS));
-    if (grid > (M + 31) / 32) grid = (M + 31) / 32;
+    const long grid = nt_dma_grid(M);
     Traced tr(K_GEMM_NT + EPI, 2.0 * M * N * K, s, gemm_bytes<A_F32, EPI>(M, N, K, e));
     hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI>), dim3((unsigned)grid), dim3(448), lds, s, (const bf16*)A, lda, W,
                        ldw, M, N, K, e);
@@ -1121,6 +1262,26 @@ hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, l
   }
 #undef SCM_CASE
   return hipErrorInvalidValue;
+}
+
+bool gemm_ln_bwd_supported(long M, int N, int K, long lda, long ldw) {
+  const long lim = 1l << 31;
+  return N <= 224 && N % 4 == 0 && K >= 128 && K % 8 == 0 && M > 0 && M * lda * 2 < lim && (long)N * ldw * 2 < lim &&
+         M * N * 4 < (1l << 30);
+}
+int gemm_ln_bwd_blocks(long M) { return (int)nt_dma_grid(M); }
+
+hipError_t gemm_ln_bwd(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s) {
+  if (!gemm_ln_bwd_supported(M, N, K, lda, ldw)) return hipErrorInvalidValue;
+  static_assert(LNB_LDS <= GD_LDS, "the epilogue's LDS lies inside the stage rings");
+  static std::atomic<unsigned long long> ready;
+  if (hipError_t err = ensure_dynamic_lds((const void*)gemm_nt_dma_kernel<EPI_LN_BWD>, (size_t)GD_LDS, ready); err != hipSuccess)
+    return err;
+  const double bytes = (double)M * K * 2 + (double)N * K * 2 + (double)M * N * (4 + (e.resid ? 4 : 0) + 4 + (e.ln_dxb ? 2 : 0));
+  Traced tr(K_GEMM_LN_BWD, 2.0 * M * N * K, s, bytes);
+  hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LN_BWD>), dim3((unsigned)nt_dma_grid(M)), dim3(448), (size_t)GD_LDS, s,
+                     (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, e);
+  return hipGetLastError();
 }
 
 hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, int ones, int T, int P, int Q,

@@ -67,6 +67,22 @@ SCM_DEV float wave_sum(float v) {
   v += __shfl_xor(v, 32);
   return v;
 }
+// The same sum (the same additions in the same pairing, so the same bits) delivered as a wave-uniform value: the row
+// totals travel to lane 63 by the two wave-level broadcasts of the DPP path (row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3) and are read from there into a scalar register -- no LDS-pipe round trip.
+template <int CTRL, int ROW_MASK>
+SCM_DEV float dpp_move_rows(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+SCM_DEV float wave_sum_uniform(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  v += dpp_move_rows<0x142, 0xA>(v);
+  v += dpp_move_rows<0x143, 0xC>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 SCM_DEV float wave_max(float v) {
   v = fmaxf(v, dpp_move<0xB1>(v));
   v = fmaxf(v, dpp_move<0x4E>(v));

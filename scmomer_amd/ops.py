@@ -149,6 +149,33 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulat
     return (dx, dxb) if with_bf16 else dx
 
 
+def gemm_ln_bwd_supported(a: torch.Tensor, w: torch.Tensor) -> bool:
+    """whether dx = dres + LN'(a @ w^T) runs as one launch (gemm_ln_bwd) for these operands"""
+    return bool(a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.stride(1) == 1 and
+                lib.scm_gemm_ln_bwd_supported(a.shape[0], w.shape[0], a.shape[1], a.stride(0), w.stride(0)))
+
+
+def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulate: bool,
+                with_bf16: bool = False, defer: Optional[list] = None):
+    """dx = dres + LN'(a @ w^T): the data-gradient product and the LayerNorm backward of a sublayer in one launch
+    (the f32 product never reaches memory).  Arguments and result as ln_bwd, with dy = a[M,K] @ w[D,K]^T."""
+    m, k = a.shape
+    d = w.shape[0]
+    assert x.shape[-1] == d and x.numel() == m * d and x.is_contiguous() and (dres is None or dres.is_contiguous())
+    dx = torch.empty_like(x)
+    dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if with_bf16 else None
+    ws = torch.empty(lib.scm_gemm_ln_bwd_ws_floats(m, d), dtype=F32, device=x.device)
+    now = defer is None
+    check(lib.scm_gemm_ln_bwd(_p(a), a.stride(0), _p(w), w.stride(0), m, d, k, _p(x), _p(mean), _p(rstd), _p(gamma),
+                              _p(dres), _p(dx), _p(dxb), _p(ws), _p(dgamma) if now else None,
+                              _p(dbeta) if now else None, _p(dres_colsum) if now else None, int(accumulate), _stream()),
+          "scm_gemm_ln_bwd")
+    if not now:
+        defer.append(colsum_job(ws, ws.numel() // (3 * d), 3 * d,
+                                [(dgamma, 0, d), (dbeta, d, 2 * d), (dres_colsum, 2 * d, 3 * d)], accumulate))
+    return (dx, dxb) if with_bf16 else dx
+
+
 # ----------------------------------------------------------------------------- linear products
 def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, *, out0: torch.Tensor, out1=None, bias=None, resid=None,
             pre=None):

@@ -244,6 +244,20 @@ def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[tor
     return y.view(b, n, d), tape
 
 
+def _dgrad_ln(a: torch.Tensor, w_t: torch.Tensor, tp, gamma, dres, dgamma, dbeta, dres_colsum, ln: bool, want_b: bool,
+              defer: Optional[list]):
+    """gradient with respect to a sublayer's input: dh = a @ w_t^T, then (ln) dx = dres + LN'(dh).  One launch where
+    the sizes allow it (the f32 dh rows stay on the chip), else the product followed by the LayerNorm backward."""
+    if not ln:
+        dh = torch.empty((a.shape[0], w_t.shape[0]), dtype=F32, device=a.device)
+        return ops.gemm_nt(ops.EPI_F32, a, w_t, out0=dh)
+    if ops.gemm_ln_bwd_supported(a, w_t) and tp.x.is_contiguous() and (dres is None or dres.is_contiguous()):
+        return ops.gemm_ln_bwd(a, w_t, tp.x, tp.mean, tp.rstd, gamma, dres, dgamma, dbeta, dres_colsum, False, want_b, defer)
+    dh = torch.empty((a.shape[0], w_t.shape[0]), dtype=F32, device=a.device)
+    ops.gemm_nt(ops.EPI_F32, a, w_t, out0=dh)
+    return ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, gamma, dres, dgamma, dbeta, dres_colsum, False, want_b, defer)
+
+
 def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
              dres: Optional[torch.Tensor], need_dx: bool, dy_b: Optional[torch.Tensor] = None, want_b: bool = False,
              defer: Optional[list] = None):
@@ -279,15 +293,11 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
                 g["bq"], g["bk"], g["bv"] = gb[:inner], gb[inner:2 * inner], gb[2 * inner:]
     dx = None
     if need_dh:
-        dh = torch.empty((t, d), dtype=F32, device=dev)
-        ops.gemm_nt(ops.EPI_F32, dqkv2, w["wqkv_t"], out0=dh)
         if ln:
             g["g1"] = torch.empty(d, dtype=F32, device=dev)
             g["b1"] = torch.empty(d, dtype=F32, device=dev)
             g["bo"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
-            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g1"], dres, g["g1"], g["b1"], g["bo"], False, want_b, defer)
-        else:
-            dx = dh
+        dx = _dgrad_ln(dqkv2, w["wqkv_t"], tp, p["g1"], dres, g.get("g1"), g.get("b1"), g.get("bo"), ln, want_b, defer)
     if need["bo"] and g.get("bo") is None:
         g["bo"] = dy.sum(0)
     return dx, g
@@ -346,15 +356,11 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
             ops.wgrad(dpre, tp.h, g["w1"], g["c1"], False, False, defer)
     dx = None
     if need_dh:
-        dh = torch.empty((t, d), dtype=F32, device=dev)
-        ops.gemm_nt(ops.EPI_F32, dpre, w["w1_t"], out0=dh)
         if ln:
             g["g2"] = torch.empty(d, dtype=F32, device=dev)
             g["b2"] = torch.empty(d, dtype=F32, device=dev)
             g["c2"] = torch.empty(d, dtype=F32, device=dev) if dres is not None else None
-            dx = ops.ln_bwd(dh, tp.x, tp.mean, tp.rstd, p["g2"], dres, g["g2"], g["b2"], g["c2"], False, want_b, defer)
-        else:
-            dx = dh
+        dx = _dgrad_ln(dpre, w["w1_t"], tp, p["g2"], dres, g.get("g2"), g.get("b2"), g.get("c2"), ln, want_b, defer)
     if need["c2"] and g.get("c2") is None:
         g["c2"] = dy.sum(0)
     return dx, g

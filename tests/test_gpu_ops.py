@@ -143,6 +143,44 @@ def test_ln_fwd_bwd(ops, t):
     assert rel_err(dc, dres.double().sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("t,k,with_res,with_b", [(1, 640, True, True), (257, 1920, True, True), (5000, 800, False, False),
+                                                 (50718, 1920, True, True), (7000, 136, True, False)])
+def test_gemm_ln_bwd_equals_product_then_ln_bwd(ops, t, k, with_res, with_b):
+    """the one-launch form (product rows kept on the chip) against scm_gemm_nt(F32) + scm_ln_bwd on the same operands:
+    the same accumulators go through the same arithmetic, so dx agrees to rounding of the fused multiply-adds; the
+    column sums are grouped differently (per workgroup of the product instead of per 64 rows)"""
+    d = 200
+    a = (rnd(t, k, seed=31) * 0.5).to(torch.bfloat16).to(DEV)
+    w = (rnd(d, k, seed=32) * 0.1).to(torch.bfloat16).to(DEV)
+    x = (rnd(t, d, seed=33) * 2 + 0.5).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd(d, seed=34)).to(DEV), (0.1 * rnd(d, seed=35)).to(DEV)
+    dres = rnd(t, d, seed=36).to(DEV) if with_res else None
+    assert ops.gemm_ln_bwd_supported(a, w)
+    _, mean, rstd = ops.ln_fwd(x, gamma, beta)
+    dh = torch.empty(t, d, device=DEV)
+    ops.gemm_nt(ops.EPI_F32, a, w, out0=dh)
+    dg0, db0, dc0 = (torch.zeros(d, device=DEV) for _ in range(3))
+    ref = ops.ln_bwd(dh, x, mean, rstd, gamma, dres, dg0, db0, dc0 if with_res else None, False, with_b)
+    dg1, db1, dc1 = (torch.full((d,), 7.0, device=DEV) for _ in range(3))
+    got = ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres, dg1, db1, dc1 if with_res else None, False, with_b)
+    if with_b:
+        assert rel_err(got[0], ref[0]) < 2e-6
+        assert rel_err(got[1].float(), ref[1].float()) < 4e-3     # a few elements round to the neighbouring bf16 value
+        assert (got[1] != ref[1]).float().mean() < 1e-3
+    else:
+        assert rel_err(got, ref) < 2e-6
+    assert rel_err(dg1, dg0) < 2e-5 and rel_err(db1, db0) < 2e-5
+    if with_res:
+        assert rel_err(dc1, dc0) < 2e-5
+    # deferred form: the column partials are summed by reduce_batch, accumulating into the outputs
+    jobs = []
+    dg2, db2 = dg1.clone(), db1.clone()
+    got2 = ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres, dg2, db2, None, True, with_b, jobs)
+    ops.reduce_batch(jobs)
+    assert torch.equal(got2[0] if with_b else got2, got[0] if with_b else got)
+    assert rel_err(dg2, 2 * dg1) < 2e-5 and rel_err(db2, 2 * db1) < 2e-5
+
+
 def test_embed_fwd_bwd_bit_exact(ops):
     b, n, d, v = 3, 501, 200, 7
     p = O.make_params(5, depth=0, max_seq_len=n)

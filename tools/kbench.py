@@ -150,3 +150,27 @@ if filt == "chain":
     print(f"one launch (saving tape, next ln)           {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=True, next_ln=(gamma, beta))) * 1e6:7.1f} us")
     print(f"one launch (no tape, next ln)               {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=False, next_ln=(gamma, beta))) * 1e6:7.1f} us")
     print(f"one launch (no tape)                        {timeit(lambda: ops.ffn_chain_fwd(x, gamma, beta, w1, b1, w2c, b2, save=False)) * 1e6:7.1f} us")
+
+# ---- data-gradient product + LayerNorm backward: one launch against the two it replaces (filter "lnfuse")
+if filt == "lnfuse":
+    x = rnd(T, D, dtype=f32); gamma = torch.ones(D, device=dev); beta = torch.zeros(D, device=dev)
+    dres = rnd(T, D, dtype=f32)
+    _, mean, rstd = ops.ln_fwd(x, gamma, beta)
+    dg, db, dc = (torch.zeros(D, device=dev) for _ in range(3))
+    for K in (1920, 800):
+        a = rnd(T, K); w = rnd(D, K)
+        dh = torch.empty(T, D, dtype=f32, device=dev)
+        jobs = []
+        def sep():
+            ops.gemm_nt(ops.EPI_F32, a, w, out0=dh)
+            ops.ln_bwd(dh, x, mean, rstd, gamma, dres, dg, db, dc, False, True, jobs); jobs.clear()
+        def one():
+            ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres, dg, db, dc, False, True, jobs); jobs.clear()
+        for name, fn in (("separate", sep), ("one launch", one)):
+            for _ in range(3): fn()
+            torch.cuda.synchronize(); ops.trace_collect(); ops.trace_enable("all")
+            for _ in range(20): fn()
+            torch.cuda.synchronize(); ops.trace_enable(None)
+            tr = ops.trace_collect()
+            print(f"K {K:5d} {name:11s} " + "  ".join(f"{k} {v[0] / v[2] * 1e3:6.1f} us" for k, v in tr.items()) +
+                  f"   total {sum(v[0] / v[2] for v in tr.values()) * 1e3:6.1f} us")
