@@ -120,6 +120,17 @@ int scm_gemm_ln_bwd(const void* A_bf16, int64_t lda, const void* W_bf16, int64_t
                     float* dx, void* dx_bf16, float* ws, float* dgamma, float* dbeta, float* dres_colsum,
                     int accumulate, void* stream);
 
+/* ---- the output product of a sublayer with the NEXT sublayer's LayerNorm as its epilogue:
+ *      y = A W^T + bias + resid (SelfAttention.to_out, performer_pytorch.py:402, or FeedForward.w2, :330, with the
+ *      residual add of reversible.py:144-145), then h = LN(y) for the PreLayerNorm (:289-295) that reads y next.
+ *      It replaces scm_gemm_nt(SCM_EPI_F32_BIAS_RES) followed by scm_ln_fwd: y is not read back.
+ *      A [M,K] bf16, W [D,K] bf16; resid (may be NULL), y: [M,D] f32, contiguous rows; h [M,D] bf16; mean, rstd [M].
+ *      Sizes: scm_gemm_res_ln_supported (D <= 220, D % 4 == 0, K >= 128, K % 8 == 0, M D < 2^28). */
+int scm_gemm_res_ln_supported(int64_t M, int D, int K, int64_t lda, int64_t ldw);
+int scm_gemm_res_ln(const void* A_bf16, int64_t lda, const void* W_bf16, int64_t ldw, int64_t M, int D, int K,
+                    const float* bias, const float* resid, float* y, const float* gamma, const float* beta,
+                    void* h_bf16, float* mean, float* rstd, void* stream);
+
 /* ---- forward of the FeedForward sublayer in one launch: PreLayerNorm(Chunk(FeedForward)),
  *      performer_pytorch.py:289-331, with the residual add of reversible.py:145.  Model dim D = 200 and a hidden
  *      width F % 8 == 0, F <= 2048 (scm_ffn_chain_supported); other sizes use scm_ln_fwd + scm_gemm_nt.

@@ -56,6 +56,8 @@ SIGNATURES = {
     "scm_ln_bwd_ws_floats": (i64, [i64, i32]),
     "scm_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "scm_gemm_ln_bwd_supported": (i32, [i64, i32, i32, i64, i64]),
+    "scm_gemm_res_ln_supported": (i32, [i64, i32, i32, i64, i64]),
+    "scm_gemm_res_ln": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "scm_gemm_ln_bwd_ws_floats": (i64, [i64, i32]),
     "scm_gemm_ln_bwd": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "scm_ln_bwd_noalloc": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp]),

@@ -49,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd", "gemm_res_ln"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -200,6 +200,27 @@ int scm_gemm_ln_bwd(const void* A, int64_t lda, const void* W, int64_t ldw, int6
     const ColsumSegs seg{{dgamma, dbeta, dres_colsum, nullptr}, {0, D, 2 * D, 0}, {D, 2 * D, 3 * D, 0}};
     SCM_HIP(colsum_reduce(ws, gemm_ln_bwd_blocks((long)M), 3 * D, seg, 3, accumulate, s), "scm_gemm_ln_bwd(column sums)");
   }
+  return 0;
+}
+
+int scm_gemm_res_ln_supported(int64_t M, int D, int K, int64_t lda, int64_t ldw) {
+  return (M > 0 && M < (1ll << 31) && D > 0 && K > 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K &&
+          gemm_res_ln_supported((long)M, D, K, (long)lda, (long)ldw)) ? 1 : 0;
+}
+
+int scm_gemm_res_ln(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int D, int K, const float* bias,
+                    const float* resid, float* y, const float* gamma, const float* beta, void* h_bf16, float* mean,
+                    float* rstd, void* stream) {
+  SCM_REQ(A && W && y && gamma && beta && h_bf16 && mean && rstd, "scm_gemm_res_ln: null pointer");
+  SCM_REQ(scm_gemm_res_ln_supported(M, D, K, lda, ldw),
+          "scm_gemm_res_ln: unsupported sizes (M=%lld D=%d K=%d): use scm_gemm_nt + scm_ln_fwd", (long long)M, D, K);
+  SCM_REQ(aligned16(A) && aligned16(W) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(h_bf16) &&
+              (!resid || aligned16(resid)) && (!bias || aligned16(bias)),
+          "scm_gemm_res_ln: unaligned pointer");
+  GemmEpi e{};
+  e.out0 = y; e.ldo0 = D; e.bias = bias; e.resid = resid; e.ldr = D;
+  e.ln_gamma = gamma; e.ln_beta = beta; e.ln_dxb = (bf16*)h_bf16; e.ln_mean_out = mean; e.ln_rstd_out = rstd;
+  SCM_HIP(gemm_res_ln(A, lda, W, ldw, (int)M, D, K, e, (hipStream_t)stream), "scm_gemm_res_ln");
   return 0;
 }
 

@@ -17,6 +17,7 @@ namespace scm {
 // gemm_nt
 // ------------------------------------------------------------------------------------------
 enum { EPI_BF16 = 0, EPI_F32_BIAS_RES = 1, EPI_GELU_DUAL = 2, EPI_DGELU = 3, EPI_F32 = 4, EPI_BF16_BIAS = 5 };
+constexpr int EPI_RES_LN = 7;   // internal: bias + residual, then the next sublayer's LayerNorm forward on the rows (gemm_res_ln)
 constexpr int EPI_LN_BWD = 6;   // internal: LayerNorm backward on the product's rows (gemm_ln_bwd), not an scm_gemm_nt epilogue
 
 constexpr int G_BM = 128;
@@ -363,6 +364,84 @@ SCM_DEV void ln_bwd_epilogue(char* smem, f32x16 (&acc)[7], long r0, long r1, int
   }
 }
 
+// LayerNorm forward of the NEXT sublayer as the epilogue of the residual product: the accumulators already hold
+// y = A W^T + bias + resid (they start at bias + resid), so the epilogue has no loads.  Rows are staged as in
+// ln_bwd_epilogue and walked with the lane = 4 columns shape of ln_fwd_kernel: y stored as f32, the row statistics by
+// two wave sums (mean, then centred squares), h = (y - mean) rstd gamma + beta stored as bf16.  Inactive lanes read the
+// first column past N, which holds exact zeros (products with zero-filled weight rows); N <= 220 keeps it staged.
+SCM_DEV void res_ln_epilogue(char* smem, f32x16 (&acc)[7], long r0, long r1, int M, int N, const GemmEpi& e) {
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  float* stage = (float*)smem + w * LNB_STAGE;
+  const bool active = 4 * l < N;
+  const int lcol = active ? 4 * l : N;
+  const uint32_t lane_off = active ? 16u * l : BUF_OOB;
+  const int base = (int)r0 + 32 * w, rend = (int)r1;
+  const uint32_t bytes4 = (uint32_t)((long)M * N * 4);
+  const brsrc rY = make_rsrc(e.out0, bytes4), rH = make_rsrc(e.ln_dxb, bytes4 / 2);
+  const brsrc rMu = make_rsrc(e.ln_mean_out, (uint32_t)M * 4), rRs = make_rsrc(e.ln_rstd_out, (uint32_t)M * 4);
+  const brsrc rG = make_rsrc(e.ln_gamma, (uint32_t)N * 4), rB = make_rsrc(e.ln_beta, (uint32_t)N * 4);
+  const f32x4 g = as_f32x4(buf_load16(rG, lane_off)), bt = as_f32x4(buf_load16(rB, lane_off));
+  const float fN = (float)N;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int col = 32 * t + (l & 31);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) stage[(acc_row(8 * p + rr, half) - 16 * p) * LNB_PITCH + col] = acc[t][8 * p + rr];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {          // four rows side by side: their eight wave sums overlap
+      f32x4 y[4];
+      float mu[4], rs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = *(const f32x4*)(stage + (4 * b + j) * LNB_PITCH + lcol);
+        mu[j] = y[j][0] + y[j][1] + y[j][2] + y[j][3];
+      }
+      // sums, division and rounding in the order of ln_fwd_kernel's row statistics: h, mean and rstd come out with the
+      // bits of the two-launch form
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mu[j] = wave_sum_uniform(mu[j]) / fN;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        {
+#pragma clang fp contract(off)   // squares rounded one by one and added in order (no fused multiply-add), as in ln_fwd_kernel
+          const float c0 = y[j][0] - mu[j], c1 = y[j][1] - mu[j], c2 = y[j][2] - mu[j], c3 = y[j][3] - mu[j];
+          const float p0 = c0 * c0, p1 = c1 * c1, p2 = c2 * c2, p3 = c3 * c3;
+          rs[j] = active ? ((p0 + p1) + p2) + p3 : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rs[j] = rsqrtf(wave_sum_uniform(rs[j]) / fN + 1e-5f);
+      float mstat = 0.f, rstat = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = base + 16 * p + 4 * b + j;       // wave-uniform
+        const uint32_t off = (row < rend ? (uint32_t)row * (uint32_t)(N * 4) : 0x40000000u) + lane_off;
+        buf_store16(rY, off, __builtin_bit_cast(u32x4, y[j]));
+        bf16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma clang fp contract(off)
+          const float t = rs[j] * (y[j][i] - mu[j]);
+          h[i] = (bf16)__builtin_fmaf(g[i], t, bt[i]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rH, (int)(off >> 1), 0, 0);
+        mstat = l == j ? mu[j] : mstat;
+        rstat = l == j ? rs[j] : rstat;
+      }
+      const int srow = base + 16 * p + 4 * b + l;
+      const int soff = (l < 4 && srow < rend) ? srow * 4 : (int)BUF_OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mstat), rMu, soff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstat), rRs, soff, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict__ A, long lda,
                                                           const bf16* __restrict__ W, long ldw, int M, int N, int K,
@@ -426,7 +505,7 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
 
   // issue order: A0 W0 A1 W1 | A2 W2 | A3 W3 | ...  (copies complete in issue order)
   issue_a(0); issue_w(0); issue_a(1); issue_w(1);
-  if (EPI == EPI_F32_BIAS_RES) {
+  if (EPI == EPI_F32_BIAS_RES || EPI == EPI_RES_LN) {
     // Y = A W^T + bias + residual: the accumulators START at bias + residual (lane = column, registers = rows; a
     // load instruction covers two rows x 128 contiguous bytes), fetched while the first k stages are in flight.
     // The epilogue then has no loads: a load issued there would wait for the stores of the previous column pair.
@@ -505,6 +584,8 @@ __global__ __launch_bounds__(448) void gemm_nt_dma_kernel(const bf16* __restrict
   __syncthreads();                          // all reads of the buffers are done: reuse them as the epilogue stage
   if constexpr (EPI == EPI_LN_BWD) {
     ln_bwd_epilogue(smem, acc, r0, r1, M, N, e);
+  } else if constexpr (EPI == EPI_RES_LN) {
+    res_ln_epilogue(smem, acc, r0, r1, M, N, e);
   } else {
     float* stage = (float*)smem + w * (32 * G_SP);
     const int mlim = (int)r1;               // rows from r1 on belong to the next workgroup
@@ -1280,6 +1361,22 @@ hipError_t gemm_ln_bwd(const void* A, long lda, const void* W, long ldw, int M, 
   const double bytes = (double)M * K * 2 + (double)N * K * 2 + (double)M * N * (4 + (e.resid ? 4 : 0) + 4 + (e.ln_dxb ? 2 : 0));
   Traced tr(K_GEMM_LN_BWD, 2.0 * M * N * K, s, bytes);
   hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LN_BWD>), dim3((unsigned)nt_dma_grid(M)), dim3(448), (size_t)GD_LDS, s,
+                     (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, e);
+  return hipGetLastError();
+}
+
+bool gemm_res_ln_supported(long M, int N, int K, long lda, long ldw) {
+  return N <= 220 && gemm_ln_bwd_supported(M, N, K, lda, ldw);
+}
+
+hipError_t gemm_res_ln(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s) {
+  if (!gemm_res_ln_supported(M, N, K, lda, ldw) || (e.resid && e.ldr != N)) return hipErrorInvalidValue;
+  static std::atomic<unsigned long long> ready;
+  if (hipError_t err = ensure_dynamic_lds((const void*)gemm_nt_dma_kernel<EPI_RES_LN>, (size_t)GD_LDS, ready); err != hipSuccess)
+    return err;
+  const double bytes = (double)M * K * 2 + (double)N * K * 2 + (double)M * N * (4 + (e.resid ? 4 : 0) + 2);
+  Traced tr(K_GEMM_RES_LN, 2.0 * M * N * K, s, bytes);
+  hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_RES_LN>), dim3((unsigned)nt_dma_grid(M)), dim3(448), (size_t)GD_LDS, s,
                      (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, e);
   return hipGetLastError();
 }

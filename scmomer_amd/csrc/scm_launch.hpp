@@ -30,6 +30,9 @@ struct GemmEpi {
   const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_gamma;
   bf16* ln_dxb;        // dx rounded to bf16 (may be null)
   float* ln_partial;   // [workgroups][3 N] column partials: sum dy*xhat, sum dy, sum dres
+  // LayerNorm-forward epilogue (gemm_res_ln): out0 = y f32 [M,N] = A W^T + bias + resid, and h = LN(y) with
+  // ln_gamma / ln_beta into ln_dxb (bf16 [M,N]), the row statistics into ln_mean_out / ln_rstd_out
+  const float* ln_beta; float* ln_mean_out; float* ln_rstd_out;
 };
 
 struct TensorBHND {  // element (b,h,n,d) at p + b*sb + h*sh + n*sn + d   (d contiguous)
@@ -83,7 +86,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
   K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_BIN, K_OMEGA_QR, K_FEATURE_MAP, K_LINEAR_ATTENTION, K_FFN_CHAIN_FWD,
-  K_REDUCE_BATCH, K_GEMM_LN_BWD, K_COUNT
+  K_REDUCE_BATCH, K_GEMM_LN_BWD, K_GEMM_RES_LN, K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
@@ -103,6 +106,10 @@ hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, l
 bool gemm_ln_bwd_supported(long M, int N, int K, long lda, long ldw);
 int gemm_ln_bwd_blocks(long M);
 hipError_t gemm_ln_bwd(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s);
+// y = A W^T + bias + resid (f32) and the following sublayer's LayerNorm h = LN(y) (bf16), mean, rstd in one launch.
+// Supported as gemm_ln_bwd, with N <= 220.
+bool gemm_res_ln_supported(long M, int N, int K, long lda, long ldw);
+hipError_t gemm_res_ln(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s);
 hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, int ones, int T, int P, int Q,
                  int slices, float* slab, hipStream_t s);
 hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, float* bias, int trans, int accumulate,

@@ -149,6 +149,27 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum, accumulat
     return (dx, dxb) if with_bf16 else dx
 
 
+def gemm_res_ln_supported(a: torch.Tensor, w: torch.Tensor) -> bool:
+    """whether y = a @ w^T + bias + resid and h = LN(y) run as one launch (gemm_res_ln) for these operands"""
+    return bool(a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.stride(1) == 1 and
+                lib.scm_gemm_res_ln_supported(a.shape[0], w.shape[0], a.shape[1], a.stride(0), w.stride(0)))
+
+
+def gemm_res_ln(a, w, bias, resid, gamma, beta):
+    """-> y f32 [M,D] = a @ w^T + bias + resid, and (h bf16, mean, rstd) = the LayerNorm of y with gamma, beta: the
+    output product of a sublayer and the next sublayer's normalisation in one launch"""
+    m, k = a.shape
+    d = w.shape[0]
+    assert resid is None or (resid.is_contiguous() and resid.numel() == m * d)
+    y = torch.empty((m, d), dtype=F32, device=a.device)
+    h = torch.empty((m, d), dtype=BF16, device=a.device)
+    mean = torch.empty(m, dtype=F32, device=a.device)
+    rstd = torch.empty(m, dtype=F32, device=a.device)
+    check(lib.scm_gemm_res_ln(_p(a), a.stride(0), _p(w), w.stride(0), m, d, k, _p(bias), _p(resid), _p(y), _p(gamma),
+                              _p(beta), _p(h), _p(mean), _p(rstd), _stream()), "scm_gemm_res_ln")
+    return y, (h, mean, rstd)
+
+
 def gemm_ln_bwd_supported(a: torch.Tensor, w: torch.Tensor) -> bool:
     """whether dx = dres + LN'(a @ w^T) runs as one launch (gemm_ln_bwd) for these operands"""
     return bool(a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.stride(1) == 1 and

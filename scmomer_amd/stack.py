@@ -212,10 +212,21 @@ def _qkv_views(qkv5):
     return tuple(qkv5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
 
 
+def _out_product(a: torch.Tensor, w: torch.Tensor, bias, resid, next_ln: Optional[tuple]):
+    """y = a @ w^T + bias + resid (f32 [T,D]); with next_ln = (gamma, beta) also the following sublayer's LayerNorm
+    (h, mean, rstd) of y -- from the same launch where the sizes allow it.  Returns (y, that tuple or None)."""
+    if next_ln is not None and ops.gemm_res_ln_supported(a, w) and (resid is None or resid.is_contiguous()):
+        return ops.gemm_res_ln(a, w, bias, resid, next_ln[0], next_ln[1])
+    y = torch.empty((a.shape[0], w.shape[0]), dtype=F32, device=a.device)
+    ops.gemm_nt(ops.EPI_F32_BIAS_RES, a, w, out0=y, bias=bias, resid=resid)
+    return y, (ops.ln_fwd(y, next_ln[0], next_ln[1]) if next_ln is not None else None)
+
+
 def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool,
-             pre_ln: Optional[tuple] = None):
-    """x: f32 [B,N,D].  Returns (y f32 [B,N,D] = resid + to_out(attn(LN(x))) + bias, tape).
-    pre_ln: (h, mean, rstd) when the producer of x already applied this sublayer's LayerNorm."""
+             pre_ln: Optional[tuple] = None, next_ln: Optional[tuple] = None):
+    """x: f32 [B,N,D].  Returns (y f32 [B,N,D] = resid + to_out(attn(LN(x))) + bias, tape, ln_y).
+    pre_ln: (h, mean, rstd) when the producer of x already applied this sublayer's LayerNorm.
+    next_ln: (gamma, beta) of the sublayer that reads y: ln_y = its (h, mean, rstd), else None."""
     b, n, d = x.shape
     t = b * n
     heads = p["heads"]
@@ -237,11 +248,9 @@ def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[tor
     o = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device)
     oc = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device) if save else None
     saved = ops.favor_fwd(q, k, v, w["omega_b"], o.permute(0, 2, 1, 3), oc.permute(0, 2, 1, 3) if save else None)
-    y = torch.empty((t, d), dtype=F32, device=x.device)
-    ops.gemm_nt(ops.EPI_F32_BIAS_RES, o.view(t, inner), w["wo"], out0=y, bias=p["bo"],
-                resid=resid.reshape(t, d) if resid is not None else None)
+    y, ln_y = _out_product(o.view(t, inner), w["wo"], p["bo"], resid.reshape(t, d) if resid is not None else None, next_ln)
     tape = AttnTape(x2 if ln else None, h, mean, rstd, qkv5, o, oc, saved, (b, n, d)) if save else None
-    return y.view(b, n, d), tape
+    return y.view(b, n, d), tape, ln_y
 
 
 def _dgrad_ln(a: torch.Tensor, w_t: torch.Tensor, tp, gamma, dres, dgamma, dbeta, dres_colsum, ln: bool, want_b: bool,
@@ -314,24 +323,25 @@ class FfnTape:
     shape: tuple
 
 
-def ffn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool):
-    """y = resid + w2(gelu(w1(LN(x)) + c1)) + c2"""
+def ffn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool,
+            pre_ln: Optional[tuple] = None, next_ln: Optional[tuple] = None):
+    """y = resid + w2(gelu(w1(LN(x)) + c1)) + c2; pre_ln, next_ln and the third result as in attn_fwd"""
     b, n, d = x.shape
     t = b * n
     f = p["w1"].shape[0]
     x2 = x.reshape(t, d)
-    if ln:
+    if pre_ln is not None:
+        h, mean, rstd = pre_ln
+    elif ln:
         h, mean, rstd = ops.ln_fwd(x2, p["g2"], p["b2"])
     else:
         h, mean, rstd = x2.to(BF16), None, None
     pre = ops.empty_rows(t, f, BF16, x.device)
     act = ops.empty_rows(t, f, BF16, x.device)
     ops.gemm_nt(ops.EPI_GELU_DUAL, h, w["w1"], out0=pre, out1=act, bias=p["c1"])
-    y = torch.empty((t, d), dtype=F32, device=x.device)
-    ops.gemm_nt(ops.EPI_F32_BIAS_RES, act, w["w2"], out0=y, bias=p["c2"],
-                resid=resid.reshape(t, d) if resid is not None else None)
+    y, ln_y = _out_product(act, w["w2"], p["c2"], resid.reshape(t, d) if resid is not None else None, next_ln)
     tape = FfnTape(x2 if ln else None, h, mean, rstd, pre, act, (b, n, d)) if save else None
-    return y.view(b, n, d), tape
+    return y.view(b, n, d), tape, ln_y
 
 
 def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, bool], *, ln: bool,
@@ -485,18 +495,22 @@ class _StackFn(torch.autograd.Function):
         for li, (ap, fp) in enumerate(spec.layers):
             aw = spec.cache.attn(li, ap)
             fw = spec.cache.ffn(li, fp)
-            x1, at = attn_fwd(x, ap, aw, ln=True, resid=x, save=spec.save, pre_ln=pre_ln)
+            b_, n_, d_ = x.shape
+            nxt = spec.layers[li + 1][0] if li + 1 < len(spec.layers) else None
+            chain = not spec.save and fp["c1"] is not None and ops.ffn_chain_supported(b_ * n_, d_, fp["w1"].shape[0])
+            # the output product of a sublayer also applies the LayerNorm of the sublayer that follows it
+            x1, at, ln2 = attn_fwd(x, ap, aw, ln=True, resid=x, save=spec.save, pre_ln=pre_ln,
+                                   next_ln=None if chain else (fp["g2"], fp["b2"]))
             pre_ln = None
-            b_, n_, d_ = x1.shape
-            if not spec.save and fp["c1"] is not None and ops.ffn_chain_supported(b_ * n_, d_, fp["w1"].shape[0]):
+            if chain:
                 # no tape: the whole FeedForward sublayer in one launch, which also applies the next layer's LayerNorm
-                nxt = spec.layers[li + 1][0] if li + 1 < len(spec.layers) else None
                 y, _, pre_ln = ops.ffn_chain_fwd(x1.reshape(b_ * n_, d_), fp["g2"], fp["b2"], fw["w1"], fp["c1"], fw["w2_c"],
                                                  fp["c2"], save=False,
                                                  next_ln=(nxt["g1"], nxt["b1"]) if nxt is not None else None)
                 x2, ft = y.view(b_, n_, d_), None
             else:
-                x2, ft = ffn_fwd(x1, fp, fw, ln=True, resid=x1, save=spec.save)
+                x2, ft, pre_ln = ffn_fwd(x1, fp, fw, ln=True, resid=x1, save=spec.save, pre_ln=ln2,
+                                         next_ln=(nxt["g1"], nxt["b1"]) if nxt is not None else None)
             tapes.append((at, ft))
             x = x2
         ctx.spec, ctx.tapes, ctx.tokens = spec, tapes, tokens

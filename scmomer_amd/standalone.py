@@ -23,7 +23,7 @@ class _BranchFn(torch.autograd.Function):
         shape = x.shape
         x3 = x.to(F32).reshape(-1, shape[-2], shape[-1]).contiguous() if x.dim() != 3 else x.to(F32).contiguous()
         fn = stack.attn_fwd if kind == "attn" else stack.ffn_fwd
-        y, tape = fn(x3, p, w, ln=ln, resid=None, save=True)
+        y, tape, _ = fn(x3, p, w, ln=ln, resid=None, save=True)
         ctx.kind, ctx.ln, ctx.p, ctx.w, ctx.keys, ctx.tape, ctx.shape = kind, ln, p, w, keys, tape, shape
         return y.view(shape)
 

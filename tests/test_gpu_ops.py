@@ -181,6 +181,26 @@ def test_gemm_ln_bwd_equals_product_then_ln_bwd(ops, t, k, with_res, with_b):
     assert rel_err(dg2, 2 * dg1) < 2e-5 and rel_err(db2, 2 * db1) < 2e-5
 
 
+@pytest.mark.parametrize("t,k,with_res", [(1, 640, True), (257, 800, True), (5000, 640, False), (50718, 800, True)])
+def test_gemm_res_ln_equals_product_then_ln_fwd(ops, t, k, with_res):
+    """one launch against scm_gemm_nt(F32_BIAS_RES) + scm_ln_fwd: y is the same accumulator, and the epilogue repeats
+    the LayerNorm kernel's arithmetic operation by operation, so every output has the same bits"""
+    d = 200
+    a = (rnd(t, k, seed=41) * 0.5).to(torch.bfloat16).to(DEV)
+    w = (rnd(d, k, seed=42) * 0.1).to(torch.bfloat16).to(DEV)
+    bias = rnd(d, seed=43).to(DEV)
+    resid = (rnd(t, d, seed=44) * 2).to(DEV) if with_res else None
+    gamma, beta = (1 + 0.1 * rnd(d, seed=45)).to(DEV), (0.1 * rnd(d, seed=46)).to(DEV)
+    assert ops.gemm_res_ln_supported(a, w)
+    y0 = torch.empty(t, d, device=DEV)
+    ops.gemm_nt(ops.EPI_F32_BIAS_RES, a, w, out0=y0, bias=bias, resid=resid)
+    h0, mean0, rstd0 = ops.ln_fwd(y0, gamma, beta)
+    y1, (h1, mean1, rstd1) = ops.gemm_res_ln(a, w, bias, resid, gamma, beta)
+    assert torch.equal(y1, y0)
+    assert torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)
+    assert torch.equal(h1, h0)
+
+
 def test_embed_fwd_bwd_bit_exact(ops):
     b, n, d, v = 3, 501, 200, 7
     p = O.make_params(5, depth=0, max_seq_len=n)

@@ -174,3 +174,24 @@ if filt == "lnfuse":
             tr = ops.trace_collect()
             print(f"K {K:5d} {name:11s} " + "  ".join(f"{k} {v[0] / v[2] * 1e3:6.1f} us" for k, v in tr.items()) +
                   f"   total {sum(v[0] / v[2] for v in tr.values()) * 1e3:6.1f} us")
+
+# ---- residual product + next LayerNorm forward: one launch against the two it replaces (filter "resln")
+if filt == "resln":
+    gamma = torch.ones(D, device=dev); beta = torch.zeros(D, device=dev); bias = rnd(D, dtype=f32)
+    resid = rnd(T, D, dtype=f32)
+    for K in (640, 800):
+        a = rnd(T, K); w = rnd(D, K)
+        y = torch.empty(T, D, dtype=f32, device=dev)
+        def sep():
+            ops.gemm_nt(ops.EPI_F32_BIAS_RES, a, w, out0=y, bias=bias, resid=resid)
+            ops.ln_fwd(y, gamma, beta)
+        def one():
+            ops.gemm_res_ln(a, w, bias, resid, gamma, beta)
+        for name, fn in (("separate", sep), ("one launch", one)):
+            for _ in range(3): fn()
+            torch.cuda.synchronize(); ops.trace_collect(); ops.trace_enable("all")
+            for _ in range(20): fn()
+            torch.cuda.synchronize(); ops.trace_enable(None)
+            tr = ops.trace_collect()
+            print(f"K {K:5d} {name:11s} " + "  ".join(f"{k} {v[0] / v[2] * 1e3:6.1f} us" for k, v in tr.items()) +
+                  f"   total {sum(v[0] / v[2] for v in tr.values()) * 1e3:6.1f} us")
