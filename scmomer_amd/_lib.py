@@ -33,6 +33,11 @@ class ReduceJob(C.Structure):
                 ("out", vp * 4), ("lo", i32 * 4), ("hi", i32 * 4)]
 
 
+class WgradItem(C.Structure):
+    """scm_wgrad_item"""
+    _fields_ = [("Pm", vp), ("ldp", i64), ("Qm", vp), ("ldq", i64), ("P", i32), ("Q", i32), ("with_bias", i32), ("ws", vp)]
+
+
 class FfnFwdArgs(C.Structure):
     """scm_ffn_fwd_args"""
     _fields_ = [("M", i64), ("D", i32), ("F", i32), ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp),
@@ -66,6 +71,7 @@ SIGNATURES = {
     "scm_ffn_chain_supported": (i32, [i64, i32, i32]),
     "scm_ffn_chain_fwd": (i32, [C.POINTER(FfnFwdArgs), vp]),
     "scm_wgrad_ws_floats": (i64, [i32, i32]),
+    "scm_wgrad_pair": (i32, [C.POINTER(WgradItem), C.POINTER(WgradItem), i64, i32, vp]),
     "scm_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, i32, i32, vp]),
     "scm_favor_make_plan": (i32, [i32, i32, i32, C.POINTER(FavorPlan)]),
     "scm_favor_ws_floats": (i64, [C.POINTER(FavorPlan)]),

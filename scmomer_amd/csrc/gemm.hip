@@ -1002,19 +1002,34 @@ constexpr int WD_QBYTES = W_BT * W_QP;            // 28 KB
 constexpr int WD_STAGE = WD_PBYTES + WD_QBYTES;   // 44 KB
 constexpr int WD_NSTAGE = 3;
 
+// One launch may carry two products over the same tokens (the two weight gradients of a sublayer): their P tiles
+// are dealt out as those of one wide product, every workgroup picks its product from its tile number.  With half
+// as many token slices per product the f32 slabs (written here, read back by the reduction) halve, and the launch's
+// fixed part (first stage, slab epilogue, drain: about 12 us) is paid once.
+struct WgradOne { const bf16* Pm; long ldp; const bf16* Qm; long ldq; float* slab; int P, Q, ones; };
+struct WgradPair { WgradOne p[2]; int n; };
+
 template <bool ONES>
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__ Pm, long ldp,
-                                                        const bf16* __restrict__ Qm, long ldq, int T, int P, int Q,
-                                                        int tiles_per_slice, float* __restrict__ slab) {
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradPair pr, int T, int tiles_per_slice) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
-  const int ptiles = (P + WD_BP - 1) / WD_BP;
+  const int ptiles0 = (pr.p[0].P + WD_BP - 1) / WD_BP;
+  const int ptiles = ptiles0 + (pr.n > 1 ? (pr.p[1].P + WD_BP - 1) / WD_BP : 0);
   int slice, ptile;
   {  // blocks b and b+8 share an XCD: the P tiles of one token slice run on one XCD and share the Q stage in its L2
     const int b = blockIdx.x, nslices = gridDim.x / ptiles, full = (nslices / 8) * 8 * ptiles;
     if (b < full) { slice = (b % 8) + 8 * (b / (8 * ptiles)); ptile = (b / 8) % ptiles; }
     else { slice = (nslices / 8) * 8 + (b - full) / ptiles; ptile = (b - full) % ptiles; }
   }
+  const bool second = ptile >= ptiles0;       // workgroup-uniform
+  if (second) ptile -= ptiles0;
+  const WgradOne& me = pr.p[second ? 1 : 0];
+  const bf16* __restrict__ Pm = me.Pm;
+  const bf16* __restrict__ Qm = me.Qm;
+  const long ldp = me.ldp, ldq = me.ldq;
+  const int P = me.P, Q = me.Q;
+  float* __restrict__ slab = me.slab;
+  const bool ones = ONES && me.ones;
   const int p0 = ptile * WD_BP;
   const int ntiles = (T + W_BT - 1) / W_BT;
   const int tile_lo = slice * tiles_per_slice;
@@ -1039,7 +1054,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
     const int off = 1024 * (7 * w + jj) + 16 * l;
     const int row = off / W_QP, chunk = (off - row * W_QP) >> 4;
     qv[jj] = chunk < qchunks ? (uint32_t)(row * ldq + 8 * chunk) * 2 : BUF_OOB;   // padding chunks receive zeros
-    qmask[jj] = !(ONES && chunk == qchunks);                                       // the ones column is kept
+    qmask[jj] = !(ones && chunk == qchunks);                                       // the ones column is kept
   }
   // copy number i (0..10) of this wave for a stage: 0..3 fill the P image, 4..10 the Q image.  A copy instruction
   // holds the wave's issue for 60-180 cycles, so the eleven copies of a stage are not issued in one burst: they are
@@ -1055,7 +1070,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
 #pragma unroll
     for (int i = i0; i < i1; ++i) issue_piece(tile, buf, i);
   };
-  if (ONES) {   // column Q of every stage = 1 (tokens past T multiply zero-filled P rows)
+  if (ONES && ones) {   // column Q of every stage = 1 (tokens past T multiply zero-filled P rows)
     for (int i = tid; i < WD_NSTAGE * W_BT; i += 256) {
       bf16x8 o;
 #pragma unroll
@@ -1163,7 +1178,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const bf16* __restrict__
   const unsigned long long st2 = __builtin_amdgcn_s_memtime(), sr2 = __builtin_amdgcn_s_memrealtime();
 #endif
   float* out = slab + (long)slice * P * W_LDSLAB;
-  const int qlim = ONES ? Q + 1 : Q;
+  const int qlim = ones ? Q + 1 : Q;
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int col = 32 * t + (l & 31);
@@ -1381,26 +1396,60 @@ hipError_t gemm_res_ln(const void* A, long lda, const void* W, long ldw, int M, 
   return hipGetLastError();
 }
 
+static hipError_t launch_wgrad_dma(const WgradPair& pr, int T, int slices, hipStream_t s) {
+  const int ntiles = (T + W_BT - 1) / W_BT;
+  const int tps = (ntiles + slices - 1) / slices;
+  const bool any_ones = pr.p[0].ones || (pr.n > 1 && pr.p[1].ones);
+  int ptiles = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < pr.n; ++i) {
+    ptiles += (pr.p[i].P + WD_BP - 1) / WD_BP;
+    flops += 2.0 * T * pr.p[i].P * pr.p[i].Q;
+    bytes += (double)T * (pr.p[i].P * 2.0 + pr.p[i].Q * 2.0) + (double)pr.p[i].P * pr.p[i].Q * 4;
+  }
+  Traced tr(any_ones ? K_WGRAD_BIAS : K_WGRAD, flops, s, bytes);
+  const size_t lds = (size_t)WD_NSTAGE * WD_STAGE;
+  static std::atomic<unsigned long long> ready[2];
+  const void* kfn = any_ones ? (const void*)wgrad_dma_kernel<true> : (const void*)wgrad_dma_kernel<false>;
+  if (hipError_t e = ensure_dynamic_lds(kfn, lds, ready[any_ones ? 1 : 0]); e != hipSuccess) return e;
+  dim3 grid(ptiles * slices);
+  if (any_ones)
+    hipLaunchKernelGGL((wgrad_dma_kernel<true>), grid, dim3(256), lds, s, pr, T, tps);
+  else
+    hipLaunchKernelGGL((wgrad_dma_kernel<false>), grid, dim3(256), lds, s, pr, T, tps);
+  return hipGetLastError();
+}
+
+bool wgrad_pair_supported(long T, long ldp0, long ldq0, long ldp1, long ldq1) {
+  const long lim = 1l << 31;
+  return T > 0 && T * ldp0 * 2 < lim && T * ldq0 * 2 < lim && T * ldp1 * 2 < lim && T * ldq1 * 2 < lim;
+}
+
+hipError_t wgrad_pair(const void* Pm0, long ldp0, const void* Qm0, long ldq0, int ones0, int P0, int Q0, float* slab0,
+                      const void* Pm1, long ldp1, const void* Qm1, long ldq1, int ones1, int P1, int Q1, float* slab1,
+                      int T, int slices, hipStream_t s) {
+  if (!wgrad_pair_supported(T, ldp0, ldq0, ldp1, ldq1)) return hipErrorInvalidValue;
+  WgradPair pr{};
+  pr.p[0] = WgradOne{(const bf16*)Pm0, ldp0, (const bf16*)Qm0, ldq0, slab0, P0, Q0, ones0};
+  pr.p[1] = WgradOne{(const bf16*)Pm1, ldp1, (const bf16*)Qm1, ldq1, slab1, P1, Q1, ones1};
+  pr.n = 2;
+  return launch_wgrad_dma(pr, T, slices, s);
+}
+
 hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, int ones, int T, int P, int Q,
                  int slices, float* slab, hipStream_t s) {
   const int ntiles = (T + W_BT - 1) / W_BT;
   const int tps = (ntiles + slices - 1) / slices;
   const bf16* Pb = (const bf16*)Pm;
-  Traced tr(ones ? K_WGRAD_BIAS : K_WGRAD, 2.0 * T * P * Q, s, (double)T * (P * 2.0 + Q * (q_f32 ? 4.0 : 2.0)) + (double)P * Q * 4);
   const long lim = 1l << 31;
   if (!q_f32 && (long)T * ldp * 2 < lim && (long)T * ldq * 2 < lim) {
     // bf16 operands: asynchronous global->LDS pipeline
-    const size_t lds = (size_t)WD_NSTAGE * WD_STAGE;
-    static std::atomic<unsigned long long> ready[2];
-    const void* kfn = ones ? (const void*)wgrad_dma_kernel<true> : (const void*)wgrad_dma_kernel<false>;
-    if (hipError_t e = ensure_dynamic_lds(kfn, lds, ready[ones ? 1 : 0]); e != hipSuccess) return e;
-    dim3 grid(((P + WD_BP - 1) / WD_BP) * slices);
-    if (ones)
-      hipLaunchKernelGGL((wgrad_dma_kernel<true>), grid, dim3(256), lds, s, Pb, ldp, (const bf16*)Qm, ldq, T, P, Q, tps, slab);
-    else
-      hipLaunchKernelGGL((wgrad_dma_kernel<false>), grid, dim3(256), lds, s, Pb, ldp, (const bf16*)Qm, ldq, T, P, Q, tps, slab);
-    return hipGetLastError();
+    WgradPair pr{};
+    pr.p[0] = WgradOne{Pb, ldp, (const bf16*)Qm, ldq, slab, P, Q, ones};
+    pr.n = 1;
+    return launch_wgrad_dma(pr, T, slices, s);
   }
+  Traced tr(ones ? K_WGRAD_BIAS : K_WGRAD, 2.0 * T * P * Q, s, (double)T * (P * 2.0 + Q * (q_f32 ? 4.0 : 2.0)) + (double)P * Q * 4);
   dim3 grid(((P + W_BP - 1) / W_BP) * slices);
   size_t lds = (size_t)W_BT * (W_PP + W_QP);
   if (q_f32 && ones)

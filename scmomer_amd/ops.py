@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import FavorPlan, FfnFwdArgs, ReduceJob, View4, check, lib
+from ._lib import FavorPlan, FfnFwdArgs, ReduceJob, View4, WgradItem, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -292,6 +292,37 @@ def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, tra
         j.kind, j.accumulate, j.src, j.S, j.P, j.Q, j.trans = 0, int(accumulate), _p(ws), s, p, q, int(trans)
         j.out[0], j.out[1] = _p(grad), _p(bias_grad)
         defer.append((j, ws))
+
+
+def wgrad_pair_supported(*mats) -> bool:
+    """the one-launch pair needs bf16 operands with contiguous last dimension, each below 2 GiB"""
+    return all(m.dtype == BF16 and m.stride(1) == 1 and m.shape[0] * m.stride(0) * 2 < (1 << 31) for m in mats)
+
+
+def wgrad_pair(first, second, accumulate: bool, defer: Optional[list] = None):
+    """two weight gradients over the same tokens in one launch; first / second = (pm, qm, grad, bias_grad, trans) as in
+    wgrad.  The slab sums go to `defer` (reduce_batch), or run right away as one batched reduction."""
+    t = first[0].shape[0]
+    assert second[0].shape[0] == t
+    ptiles = sum((it[0].shape[1] + 127) // 128 for it in (first, second))
+    s = max(1, min((t + 63) // 64, 256 // ptiles))
+    items, jobs = [], []
+    for pm, qm, grad, bias_grad, trans in (first, second):
+        p, q = pm.shape[1], qm.shape[1]
+        ws = torch.empty(lib.scm_wgrad_ws_floats(p, s), dtype=F32, device=pm.device)
+        it = WgradItem()
+        it.Pm, it.ldp, it.Qm, it.ldq, it.P, it.Q = _p(pm), pm.stride(0), _p(qm), qm.stride(0), p, q
+        it.with_bias, it.ws = int(bias_grad is not None), _p(ws)
+        items.append(it)
+        j = ReduceJob()
+        j.kind, j.accumulate, j.src, j.S, j.P, j.Q, j.trans = 0, int(accumulate), _p(ws), s, p, q, int(trans)
+        j.out[0], j.out[1] = _p(grad), _p(bias_grad)
+        jobs.append((j, ws))
+    check(lib.scm_wgrad_pair(items[0], items[1], t, s, _stream()), "scm_wgrad_pair")
+    if defer is not None:
+        defer.extend(jobs)
+    else:
+        reduce_batch(jobs)
 
 
 def colsum_job(ws: torch.Tensor, rows: int, width: int, segs, accumulate: bool):

@@ -280,10 +280,14 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
     inner = heads * ops.DIM_HEAD
     dev = dy.device
     g: Dict[str, torch.Tensor] = {}
+    need_qkv_w = need["wq"] or need["wk"] or need["wv"] or need["bq"]
+    # the two weight gradients of the sublayer (to_out; to_q/k/v) go out as ONE launch once both operand pairs exist
+    wo_ops = (tp.o.view(t, inner), dy if dy_b is None else dy_b)
+    pair = need["wo"] and need_qkv_w and ops.wgrad_pair_supported(*wo_ops, tp.h)
     if need["wo"]:
         g["wo"] = torch.empty((d, inner), dtype=F32, device=dev)
-        ops.wgrad(tp.o.view(t, inner), dy if dy_b is None else dy_b, g["wo"], None, True, False, defer)
-    need_qkv_w = need["wq"] or need["wk"] or need["wv"] or need["bq"]
+        if not pair:
+            ops.wgrad(*wo_ops, g["wo"], None, True, False, defer)
     need_dh = need_dx or (ln and (need["g1"] or need["b1"]))
     if need_qkv_w or need_dh:
         do = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=dev)
@@ -296,7 +300,10 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
         if need_qkv_w:
             gw = torch.empty((3 * inner, d), dtype=F32, device=dev)
             gb = torch.empty(3 * inner, dtype=F32, device=dev) if w["bqkv"] is not None else None
-            ops.wgrad(dqkv2, tp.h, gw, gb, False, False, defer)
+            if pair:
+                ops.wgrad_pair((*wo_ops, g["wo"], None, True), (dqkv2, tp.h, gw, gb, False), False, defer)
+            else:
+                ops.wgrad(dqkv2, tp.h, gw, gb, False, False, defer)
             g["wq"], g["wk"], g["wv"] = gw[:inner], gw[inner:2 * inner], gw[2 * inner:]
             if gb is not None:
                 g["bq"], g["bk"], g["bv"] = gb[:inner], gb[inner:2 * inner], gb[2 * inner:]
@@ -353,9 +360,12 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
     f = p["w1"].shape[0]
     dev = dy.device
     g: Dict[str, torch.Tensor] = {}
+    w2_ops = (tp.act, dy if dy_b is None else dy_b)
+    pair = need["w2"] and (need["w1"] or need["c1"]) and ops.wgrad_pair_supported(*w2_ops, tp.h)
     if need["w2"]:
         g["w2"] = torch.empty((d, f), dtype=F32, device=dev)
-        ops.wgrad(tp.act, dy if dy_b is None else dy_b, g["w2"], None, True, False, defer)
+        if not pair:
+            ops.wgrad(*w2_ops, g["w2"], None, True, False, defer)
     need_dh = need_dx or (ln and (need["g2"] or need["b2"]))
     if need["w1"] or need["c1"] or need_dh:
         dpre = ops.empty_rows(t, f, BF16, dev)
@@ -363,7 +373,10 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
         if need["w1"] or need["c1"]:
             g["w1"] = torch.empty((f, d), dtype=F32, device=dev)
             g["c1"] = torch.empty(f, dtype=F32, device=dev)
-            ops.wgrad(dpre, tp.h, g["w1"], g["c1"], False, False, defer)
+            if pair:    # w2's and w1's weight gradients in one launch
+                ops.wgrad_pair((*w2_ops, g["w2"], None, True), (dpre, tp.h, g["w1"], g["c1"], False), False, defer)
+            else:
+                ops.wgrad(dpre, tp.h, g["w1"], g["c1"], False, False, defer)
     dx = None
     if need_dh:
         if ln:

@@ -195,3 +195,24 @@ if filt == "resln":
             tr = ops.trace_collect()
             print(f"K {K:5d} {name:11s} " + "  ".join(f"{k} {v[0] / v[2] * 1e3:6.1f} us" for k, v in tr.items()) +
                   f"   total {sum(v[0] / v[2] for v in tr.values()) * 1e3:6.1f} us")
+
+# ---- two weight gradients in one launch against two launches, reductions included (filter "wpair2")
+if filt == "wpair2":
+    for (pa, pb, bias) in ((800, 800, True), (640, 1920, False)):
+        pm0, pm1, q0, q1 = rnd(T, pa), rnd(T, pb), rnd(T, 200), rnd(T, 200)
+        g0 = torch.zeros(200, pa, device=dev); g1 = torch.zeros(pb, 200, device=dev)
+        b1 = torch.zeros(pb, device=dev) if bias else None
+        def two():
+            jobs = []
+            ops.wgrad(pm0, q0, g0, None, True, False, jobs); ops.wgrad(pm1, q1, g1, b1, False, False, jobs); ops.reduce_batch(jobs)
+        def one():
+            jobs = []
+            ops.wgrad_pair((pm0, q0, g0, None, True), (pm1, q1, g1, b1, False), False, jobs); ops.reduce_batch(jobs)
+        for name, fn in (("two launches", two), ("one launch", one)):
+            for _ in range(3): fn()
+            torch.cuda.synchronize(); ops.trace_collect(); ops.trace_enable("all")
+            for _ in range(20): fn()
+            torch.cuda.synchronize(); ops.trace_enable(None)
+            tr = ops.trace_collect()
+            print(f"P {pa}+{pb} {name:12s} " + "  ".join(f"{k} {v[0] / 20 * 1e3:6.1f} us" for k, v in tr.items()) +
+                  f"   total {sum(v[0] / 20 for v in tr.values()) * 1e3:6.1f} us")
