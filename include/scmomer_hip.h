@@ -167,18 +167,19 @@ int64_t scm_wgrad_ws_floats(int P, int slices);
 int scm_wgrad(const void* Pm_bf16, int64_t ldp, const void* Qm, int64_t ldq, int q_f32, int64_t T, int P, int Q,
               int slices, float* ws, float* grad, float* bias_grad, int trans, int accumulate, void* stream);
 
-/* Two weight gradients over the same T tokens in one launch (the two Linear layers of a sublayer: to_out with
- * to_q/k/v, performer_pytorch.py:374-376,402; w2 with w1, :323,330): bf16 operands only.  Each item's slice partials
+/* Up to four weight gradients over the same T tokens in one launch (the Linear layers of a layer: to_out and
+ * to_q/k/v, performer_pytorch.py:374-376,402; w2 and w1, :323,330): bf16 operands only.  Each item's slice partials
  * are left in its ws ([slices][P][208] f32, scm_wgrad_ws_floats(P, slices) floats, the bias column at index Q when
- * with_bias) for scm_reduce_batch, exactly as scm_wgrad leaves them with grad == NULL.  With half as many slices per
- * product as two separate calls would use, half as many partials are written and read back. */
+ * with_bias) for scm_reduce_batch, exactly as scm_wgrad leaves them with grad == NULL.  The P tiles (128 wide) of all
+ * items share one round of workgroups, so `slices` is chosen for their total (about 256 / total tiles): fewer slices
+ * per product than separate calls would use, so fewer partials written and read back, and one launch. */
 typedef struct scm_wgrad_item {
   const void* Pm; int64_t ldp;   /* [T,P] bf16 */
   const void* Qm; int64_t ldq;   /* [T,Q] bf16 */
   int P, Q, with_bias;
   float* ws;
 } scm_wgrad_item;
-int scm_wgrad_pair(const scm_wgrad_item* a, const scm_wgrad_item* b, int64_t T, int slices, void* stream);
+int scm_wgrad_multi(const scm_wgrad_item* items, int n, int64_t T, int slices, void* stream);
 
 /* ---- deferred reductions: one launch for the small reductions that end the gradient kernels ----------------
  * A backward pass runs some forty of them (24 weight-gradient slab sums, 14 column sums); each is a few microseconds

@@ -71,7 +71,7 @@ SIGNATURES = {
     "scm_ffn_chain_supported": (i32, [i64, i32, i32]),
     "scm_ffn_chain_fwd": (i32, [C.POINTER(FfnFwdArgs), vp]),
     "scm_wgrad_ws_floats": (i64, [i32, i32]),
-    "scm_wgrad_pair": (i32, [C.POINTER(WgradItem), C.POINTER(WgradItem), i64, i32, vp]),
+    "scm_wgrad_multi": (i32, [C.POINTER(WgradItem), i32, i64, i32, vp]),
     "scm_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, i32, i32, vp]),
     "scm_favor_make_plan": (i32, [i32, i32, i32, C.POINTER(FavorPlan)]),
     "scm_favor_ws_floats": (i64, [C.POINTER(FavorPlan)]),

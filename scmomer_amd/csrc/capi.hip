@@ -279,22 +279,23 @@ int scm_ffn_chain_fwd(const scm_ffn_fwd_args* p, void* stream) {
   return 0;
 }
 
-int scm_wgrad_pair(const scm_wgrad_item* a, const scm_wgrad_item* b, int64_t T, int slices, void* stream) {
-  SCM_REQ(a && b, "scm_wgrad_pair: null item");
-  for (const scm_wgrad_item* it : {a, b}) {
-    SCM_REQ(it->Pm && it->Qm && it->ws, "scm_wgrad_pair: null pointer");
+int scm_wgrad_multi(const scm_wgrad_item* items, int n, int64_t T, int slices, void* stream) {
+  SCM_REQ(items && n >= 1 && n <= 4, "scm_wgrad_multi: need 1..4 items");
+  SCM_REQ(T > 0 && T < (1ll << 31) && slices > 0, "scm_wgrad_multi: bad T or slices");
+  WgradDesc d[4];
+  for (int i = 0; i < n; ++i) {
+    const scm_wgrad_item* it = items + i;
+    SCM_REQ(it->Pm && it->Qm && it->ws, "scm_wgrad_multi: null pointer");
     SCM_REQ(it->P > 0 && it->P % 8 == 0 && it->Q > 0 && it->Q <= 200 && it->Q % 8 == 0,
-            "scm_wgrad_pair: need P%%8==0, Q<=200, Q%%8==0 (P=%d Q=%d)", it->P, it->Q);
+            "scm_wgrad_multi: need P%%8==0, Q<=200, Q%%8==0 (P=%d Q=%d)", it->P, it->Q);
     SCM_REQ(it->ldp >= it->P && it->ldq >= it->Q && it->ldp % 8 == 0 && it->ldq % 8 == 0 && aligned16(it->Pm) &&
                 aligned16(it->Qm),
-            "scm_wgrad_pair: bad leading dimension or alignment");
+            "scm_wgrad_multi: bad leading dimension or alignment");
+    SCM_REQ(T * it->ldp * 2 < (1ll << 31) && T * it->ldq * 2 < (1ll << 31),
+            "scm_wgrad_multi: operands of 2 GiB or more: use scm_wgrad");
+    d[i] = WgradDesc{it->Pm, (long)it->ldp, it->Qm, (long)it->ldq, it->ws, it->P, it->Q, it->with_bias ? 1 : 0};
   }
-  SCM_REQ(T > 0 && T < (1ll << 31) && slices > 0, "scm_wgrad_pair: bad T or slices");
-  SCM_REQ(wgrad_pair_supported((long)T, a->ldp, a->ldq, b->ldp, b->ldq),
-          "scm_wgrad_pair: operands of 2 GiB or more: use scm_wgrad");
-  SCM_HIP(wgrad_pair(a->Pm, a->ldp, a->Qm, a->ldq, a->with_bias ? 1 : 0, a->P, a->Q, a->ws, b->Pm, b->ldp, b->Qm,
-                     b->ldq, b->with_bias ? 1 : 0, b->P, b->Q, b->ws, (int)T, slices, (hipStream_t)stream),
-          "scm_wgrad_pair");
+  SCM_HIP(wgrad_multi(d, n, (int)T, slices, (hipStream_t)stream), "scm_wgrad_multi");
   return 0;
 }
 

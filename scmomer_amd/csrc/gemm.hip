@@ -1002,28 +1002,34 @@ constexpr int WD_QBYTES = W_BT * W_QP;            // 28 KB
 constexpr int WD_STAGE = WD_PBYTES + WD_QBYTES;   // 44 KB
 constexpr int WD_NSTAGE = 3;
 
-// One launch may carry two products over the same tokens (the two weight gradients of a sublayer): their P tiles
-// are dealt out as those of one wide product, every workgroup picks its product from its tile number.  With half
-// as many token slices per product the f32 slabs (written here, read back by the reduction) halve, and the launch's
-// fixed part (first stage, slab epilogue, drain: about 12 us) is paid once.
+// One launch may carry up to four products over the same tokens (the weight gradients of a layer): their P tiles
+// are dealt out as those of one wide product, every workgroup picks its product from its tile number.  With fewer
+// token slices per product the f32 slabs (written here, read back by the reduction) shrink in proportion, and the
+// launch's fixed part (first stage, slab epilogue, drain: about 12 us) is paid once.
 struct WgradOne { const bf16* Pm; long ldp; const bf16* Qm; long ldq; float* slab; int P, Q, ones; };
-struct WgradPair { WgradOne p[2]; int n; };
+constexpr int WD_MAXN = 4;
+struct WgradPair { WgradOne p[WD_MAXN]; int n; };
 
 template <bool ONES>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradPair pr, int T, int tiles_per_slice) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
-  const int ptiles0 = (pr.p[0].P + WD_BP - 1) / WD_BP;
-  const int ptiles = ptiles0 + (pr.n > 1 ? (pr.p[1].P + WD_BP - 1) / WD_BP : 0);
+  int ptiles = 0;
+#pragma unroll
+  for (int i = 0; i < WD_MAXN; ++i) ptiles += i < pr.n ? (pr.p[i].P + WD_BP - 1) / WD_BP : 0;
   int slice, ptile;
   {  // blocks b and b+8 share an XCD: the P tiles of one token slice run on one XCD and share the Q stage in its L2
     const int b = blockIdx.x, nslices = gridDim.x / ptiles, full = (nslices / 8) * 8 * ptiles;
     if (b < full) { slice = (b % 8) + 8 * (b / (8 * ptiles)); ptile = (b / 8) % ptiles; }
     else { slice = (nslices / 8) * 8 + (b - full) / ptiles; ptile = (b - full) % ptiles; }
   }
-  const bool second = ptile >= ptiles0;       // workgroup-uniform
-  if (second) ptile -= ptiles0;
-  const WgradOne& me = pr.p[second ? 1 : 0];
+  int which = 0;                              // workgroup-uniform: the product this tile number falls into
+#pragma unroll
+  for (int i = 0; i < WD_MAXN - 1; ++i) {
+    const int pt = (pr.p[i].P + WD_BP - 1) / WD_BP;
+    if (which == i && i + 1 < pr.n && ptile >= pt) { ptile -= pt; which = i + 1; }
+  }
+  const WgradOne& me = pr.p[which];
   const bf16* __restrict__ Pm = me.Pm;
   const bf16* __restrict__ Qm = me.Qm;
   const long ldp = me.ldp, ldq = me.ldq;
@@ -1399,7 +1405,8 @@ hipError_t gemm_res_ln(const void* A, long lda, const void* W, long ldw, int M, 
 static hipError_t launch_wgrad_dma(const WgradPair& pr, int T, int slices, hipStream_t s) {
   const int ntiles = (T + W_BT - 1) / W_BT;
   const int tps = (ntiles + slices - 1) / slices;
-  const bool any_ones = pr.p[0].ones || (pr.n > 1 && pr.p[1].ones);
+  bool any_ones = false;
+  for (int i = 0; i < pr.n; ++i) any_ones = any_ones || pr.p[i].ones;
   int ptiles = 0;
   double flops = 0, bytes = 0;
   for (int i = 0; i < pr.n; ++i) {
@@ -1420,19 +1427,15 @@ static hipError_t launch_wgrad_dma(const WgradPair& pr, int T, int slices, hipSt
   return hipGetLastError();
 }
 
-bool wgrad_pair_supported(long T, long ldp0, long ldq0, long ldp1, long ldq1) {
+hipError_t wgrad_multi(const WgradDesc* d, int n, int T, int slices, hipStream_t s) {
+  if (n < 1 || n > WD_MAXN) return hipErrorInvalidValue;
   const long lim = 1l << 31;
-  return T > 0 && T * ldp0 * 2 < lim && T * ldq0 * 2 < lim && T * ldp1 * 2 < lim && T * ldq1 * 2 < lim;
-}
-
-hipError_t wgrad_pair(const void* Pm0, long ldp0, const void* Qm0, long ldq0, int ones0, int P0, int Q0, float* slab0,
-                      const void* Pm1, long ldp1, const void* Qm1, long ldq1, int ones1, int P1, int Q1, float* slab1,
-                      int T, int slices, hipStream_t s) {
-  if (!wgrad_pair_supported(T, ldp0, ldq0, ldp1, ldq1)) return hipErrorInvalidValue;
   WgradPair pr{};
-  pr.p[0] = WgradOne{(const bf16*)Pm0, ldp0, (const bf16*)Qm0, ldq0, slab0, P0, Q0, ones0};
-  pr.p[1] = WgradOne{(const bf16*)Pm1, ldp1, (const bf16*)Qm1, ldq1, slab1, P1, Q1, ones1};
-  pr.n = 2;
+  for (int i = 0; i < n; ++i) {
+    if ((long)T * d[i].ldp * 2 >= lim || (long)T * d[i].ldq * 2 >= lim) return hipErrorInvalidValue;
+    pr.p[i] = WgradOne{(const bf16*)d[i].Pm, d[i].ldp, (const bf16*)d[i].Qm, d[i].ldq, d[i].slab, d[i].P, d[i].Q, d[i].ones};
+  }
+  pr.n = n;
   return launch_wgrad_dma(pr, T, slices, s);
 }
 

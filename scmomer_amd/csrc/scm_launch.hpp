@@ -112,11 +112,10 @@ bool gemm_res_ln_supported(long M, int N, int K, long lda, long ldw);
 hipError_t gemm_res_ln(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s);
 hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, int ones, int T, int P, int Q,
                  int slices, float* slab, hipStream_t s);
-// two weight gradients over the same T tokens in one launch (bf16 operands), slice partials left in slab0 / slab1
-bool wgrad_pair_supported(long T, long ldp0, long ldq0, long ldp1, long ldq1);
-hipError_t wgrad_pair(const void* Pm0, long ldp0, const void* Qm0, long ldq0, int ones0, int P0, int Q0, float* slab0,
-                      const void* Pm1, long ldp1, const void* Qm1, long ldq1, int ones1, int P1, int Q1, float* slab1,
-                      int T, int slices, hipStream_t s);
+// up to four weight gradients over the same T tokens in one launch (bf16 operands, each below 2 GiB), slice partials
+// left in each product's slab
+struct WgradDesc { const void* Pm; long ldp; const void* Qm; long ldq; float* slab; int P, Q, ones; };
+hipError_t wgrad_multi(const WgradDesc* d, int n, int T, int slices, hipStream_t s);
 hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, float* bias, int trans, int accumulate,
                         hipStream_t s);
 hipError_t cast_weight(const float* src, int R, int C, void* dst, void* dstT, hipStream_t s);

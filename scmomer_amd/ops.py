@@ -294,31 +294,30 @@ def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, tra
         defer.append((j, ws))
 
 
-def wgrad_pair_supported(*mats) -> bool:
-    """the one-launch pair needs bf16 operands with contiguous last dimension, each below 2 GiB"""
+def wgrad_multi_supported(*mats) -> bool:
+    """the shared launch needs bf16 operands with contiguous last dimension, each below 2 GiB"""
     return all(m.dtype == BF16 and m.stride(1) == 1 and m.shape[0] * m.stride(0) * 2 < (1 << 31) for m in mats)
 
 
-def wgrad_pair(first, second, accumulate: bool, defer: Optional[list] = None):
-    """two weight gradients over the same tokens in one launch; first / second = (pm, qm, grad, bias_grad, trans) as in
-    wgrad.  The slab sums go to `defer` (reduce_batch), or run right away as one batched reduction."""
-    t = first[0].shape[0]
-    assert second[0].shape[0] == t
-    ptiles = sum((it[0].shape[1] + 127) // 128 for it in (first, second))
+def wgrad_multi(products, accumulate: bool, defer: Optional[list] = None):
+    """up to four weight gradients over the same tokens in one launch; products = [(pm, qm, grad, bias_grad, trans)]
+    as in wgrad.  The slab sums go to `defer` (reduce_batch), or run right away as one batched reduction."""
+    assert 1 <= len(products) <= 4
+    t = products[0][0].shape[0]
+    ptiles = sum((it[0].shape[1] + 127) // 128 for it in products)
     s = max(1, min((t + 63) // 64, 256 // ptiles))
-    items, jobs = [], []
-    for pm, qm, grad, bias_grad, trans in (first, second):
+    items, jobs = (WgradItem * len(products))(), []
+    for it, (pm, qm, grad, bias_grad, trans) in zip(items, products):
+        assert pm.shape[0] == t and qm.shape[0] == t
         p, q = pm.shape[1], qm.shape[1]
         ws = torch.empty(lib.scm_wgrad_ws_floats(p, s), dtype=F32, device=pm.device)
-        it = WgradItem()
         it.Pm, it.ldp, it.Qm, it.ldq, it.P, it.Q = _p(pm), pm.stride(0), _p(qm), qm.stride(0), p, q
         it.with_bias, it.ws = int(bias_grad is not None), _p(ws)
-        items.append(it)
         j = ReduceJob()
         j.kind, j.accumulate, j.src, j.S, j.P, j.Q, j.trans = 0, int(accumulate), _p(ws), s, p, q, int(trans)
         j.out[0], j.out[1] = _p(grad), _p(bias_grad)
         jobs.append((j, ws))
-    check(lib.scm_wgrad_pair(items[0], items[1], t, s, _stream()), "scm_wgrad_pair")
+    check(lib.scm_wgrad_multi(items, len(products), t, s, _stream()), "scm_wgrad_multi")
     if defer is not None:
         defer.extend(jobs)
     else:

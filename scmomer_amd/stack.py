@@ -283,7 +283,7 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
     need_qkv_w = need["wq"] or need["wk"] or need["wv"] or need["bq"]
     # the two weight gradients of the sublayer (to_out; to_q/k/v) go out as ONE launch once both operand pairs exist
     wo_ops = (tp.o.view(t, inner), dy if dy_b is None else dy_b)
-    pair = need["wo"] and need_qkv_w and ops.wgrad_pair_supported(*wo_ops, tp.h)
+    pair = need["wo"] and need_qkv_w and ops.wgrad_multi_supported(*wo_ops, tp.h)
     if need["wo"]:
         g["wo"] = torch.empty((d, inner), dtype=F32, device=dev)
         if not pair:
@@ -301,7 +301,7 @@ def attn_bwd(dy: torch.Tensor, tp: AttnTape, p: dict, w: dict, need: Dict[str, b
             gw = torch.empty((3 * inner, d), dtype=F32, device=dev)
             gb = torch.empty(3 * inner, dtype=F32, device=dev) if w["bqkv"] is not None else None
             if pair:
-                ops.wgrad_pair((*wo_ops, g["wo"], None, True), (dqkv2, tp.h, gw, gb, False), False, defer)
+                ops.wgrad_multi([(*wo_ops, g["wo"], None, True), (dqkv2, tp.h, gw, gb, False)], False, defer)
             else:
                 ops.wgrad(dqkv2, tp.h, gw, gb, False, False, defer)
             g["wq"], g["wk"], g["wv"] = gw[:inner], gw[inner:2 * inner], gw[2 * inner:]
@@ -361,7 +361,7 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
     dev = dy.device
     g: Dict[str, torch.Tensor] = {}
     w2_ops = (tp.act, dy if dy_b is None else dy_b)
-    pair = need["w2"] and (need["w1"] or need["c1"]) and ops.wgrad_pair_supported(*w2_ops, tp.h)
+    pair = need["w2"] and (need["w1"] or need["c1"]) and ops.wgrad_multi_supported(*w2_ops, tp.h)
     if need["w2"]:
         g["w2"] = torch.empty((d, f), dtype=F32, device=dev)
         if not pair:
@@ -374,7 +374,7 @@ def ffn_bwd(dy: torch.Tensor, tp: FfnTape, p: dict, w: dict, need: Dict[str, boo
             g["w1"] = torch.empty((f, d), dtype=F32, device=dev)
             g["c1"] = torch.empty(f, dtype=F32, device=dev)
             if pair:    # w2's and w1's weight gradients in one launch
-                ops.wgrad_pair((*w2_ops, g["w2"], None, True), (dpre, tp.h, g["w1"], g["c1"], False), False, defer)
+                ops.wgrad_multi([(*w2_ops, g["w2"], None, True), (dpre, tp.h, g["w1"], g["c1"], False)], False, defer)
             else:
                 ops.wgrad(dpre, tp.h, g["w1"], g["c1"], False, False, defer)
     dx = None

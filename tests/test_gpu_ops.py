@@ -121,28 +121,36 @@ def test_wgrad(ops, t, p, q_f32, trans, with_bias):
 
 
 @pytest.mark.parametrize("t,p0,p1", [(1000, 640, 1920), (50718, 800, 800), (130, 160, 640), (4097, 1920, 800)])
-def test_wgrad_pair_equals_two_calls(ops, t, p0, p1):
-    """two products in one launch against scm_wgrad twice: the same kernel code per product; only the token slices
-    (so the grouping of the f32 partial sums) differ"""
+def test_wgrad_multi_equals_separate_calls(ops, t, p0, p1):
+    """several products in one launch against scm_wgrad per product: the same kernel code per product; only the token
+    slices (so the grouping of the f32 partial sums) differ"""
     q = 200
     pm0 = (rnd(t, p0, seed=51) * 0.5).to(torch.bfloat16).to(DEV)
     pm1 = (rnd(t, p1, seed=52) * 0.5).to(torch.bfloat16).to(DEV)
     qm0 = (rnd(t, q, seed=53) * 0.5).to(torch.bfloat16).to(DEV)
     qm1 = (rnd(t, q, seed=54) * 0.5).to(torch.bfloat16).to(DEV)
-    assert ops.wgrad_pair_supported(pm0, qm0, pm1, qm1)
+    assert ops.wgrad_multi_supported(pm0, qm0, pm1, qm1)
     g0r, g1r = torch.zeros(q, p0, device=DEV), torch.zeros(p1, q, device=DEV)
     b1r = torch.zeros(p1, device=DEV)
     ops.wgrad(pm0, qm0, g0r, None, True, False)
     ops.wgrad(pm1, qm1, g1r, b1r, False, False)
     g0, g1, b1 = torch.full_like(g0r, 3.0), torch.full_like(g1r, 3.0), torch.full_like(b1r, 3.0)
-    ops.wgrad_pair((pm0, qm0, g0, None, True), (pm1, qm1, g1, b1, False), False)
+    ops.wgrad_multi([(pm0, qm0, g0, None, True), (pm1, qm1, g1, b1, False)], False)
     assert rel_err(g0, g0r) < 2e-5 and rel_err(g1, g1r) < 2e-5 and rel_err(b1, b1r) < 2e-5
     want = pm1.double().t() @ qm1.double()
     assert rel_err(g1, want) < 3e-5
     jobs = []
-    ops.wgrad_pair((pm0, qm0, g0, None, True), (pm1, qm1, g1, b1, False), True, jobs)
+    ops.wgrad_multi([(pm0, qm0, g0, None, True), (pm1, qm1, g1, b1, False)], True, jobs)
     ops.reduce_batch(jobs)
     assert rel_err(g0, 2 * g0r) < 2e-5 and rel_err(b1, 2 * b1r) < 2e-5
+    # four products (a whole layer's weight gradients), the third and fourth repeating the first two with swapped roles
+    g2, b2, g3 = torch.zeros(p0, q, device=DEV), torch.zeros(p0, device=DEV), torch.zeros(q, p1, device=DEV)
+    g0.zero_(); g1.zero_(); b1.zero_()
+    ops.wgrad_multi([(pm0, qm0, g0, None, True), (pm1, qm1, g1, b1, False), (pm0, qm1, g2, b2, False),
+                     (pm1, qm0, g3, None, True)], False)
+    assert rel_err(g0, g0r) < 2e-5 and rel_err(g1, g1r) < 2e-5 and rel_err(b1, b1r) < 2e-5
+    assert rel_err(g2, pm0.double().t() @ qm1.double()) < 3e-5 and rel_err(b2, pm0.double().sum(0)) < 3e-5
+    assert rel_err(g3, qm0.double().t() @ pm1.double()) < 3e-5
 
 
 # --------------------------------------------------------------------------------------- rows

@@ -207,7 +207,7 @@ if filt == "wpair2":
             ops.wgrad(pm0, q0, g0, None, True, False, jobs); ops.wgrad(pm1, q1, g1, b1, False, False, jobs); ops.reduce_batch(jobs)
         def one():
             jobs = []
-            ops.wgrad_pair((pm0, q0, g0, None, True), (pm1, q1, g1, b1, False), False, jobs); ops.reduce_batch(jobs)
+            ops.wgrad_multi([(pm0, q0, g0, None, True), (pm1, q1, g1, b1, False)], False, jobs); ops.reduce_batch(jobs)
         for name, fn in (("two launches", two), ("one launch", one)):
             for _ in range(3): fn()
             torch.cuda.synchronize(); ops.trace_collect(); ops.trace_enable("all")
@@ -216,3 +216,25 @@ if filt == "wpair2":
             tr = ops.trace_collect()
             print(f"P {pa}+{pb} {name:12s} " + "  ".join(f"{k} {v[0] / 20 * 1e3:6.1f} us" for k, v in tr.items()) +
                   f"   total {sum(v[0] / 20 for v in tr.values()) * 1e3:6.1f} us")
+
+# ---- a layer's four weight gradients: two paired launches against one (filter "wquad")
+if filt == "wquad":
+    pa, pb, pc, pd = rnd(T, 800), rnd(T, 800), rnd(T, 640), rnd(T, 1920)
+    qs = [rnd(T, 200) for _ in range(4)]
+    ga, gb_, gc, gd = torch.zeros(200, 800, device=dev), torch.zeros(800, 200, device=dev), torch.zeros(200, 640, device=dev), torch.zeros(1920, 200, device=dev)
+    bb = torch.zeros(800, device=dev)
+    A, B, Cc, Dd = (pa, qs[0], ga, None, True), (pb, qs[1], gb_, bb, False), (pc, qs[2], gc, None, True), (pd, qs[3], gd, None, False)
+    def pairs():
+        jobs = []
+        ops.wgrad_multi([A, B], False, jobs); ops.wgrad_multi([Cc, Dd], False, jobs); ops.reduce_batch(jobs)
+    def quad():
+        jobs = []
+        ops.wgrad_multi([A, B, Cc, Dd], False, jobs); ops.reduce_batch(jobs)
+    for name, fn in (("two pairs", pairs), ("one launch", quad)):
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); ops.trace_collect(); ops.trace_enable("all")
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); ops.trace_enable(None)
+        tr = ops.trace_collect()
+        print(f"{name:12s} " + "  ".join(f"{k} {v[0] / 20 * 1e3:6.1f} us" for k, v in tr.items()) +
+              f"   total {sum(v[0] / 20 for v in tr.values()) * 1e3:6.1f} us")
