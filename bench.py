@@ -126,7 +126,8 @@ TRACE_SYMBOL = {"favor_apply_fwd": "favor_apply_kernel<0>", "favor_apply_bwd_q":
                 "wgrad/bias": "wgrad_dma_kernel<true>", "gemm_nt/f32_bias_res": "gemm_nt_dma_kernel<1>",
                 "gemm_nt/f32": "gemm_nt_dma_kernel<4>", "gemm_skinny/bf16": "gemm_skinny_kernel<false, 0>",
                 "gemm_skinny/gelu_dual": "gemm_skinny_kernel<false, 2>", "gemm_skinny/dgelu": "gemm_skinny_kernel<false, 3>",
-                "ffn_chain_fwd": "ffn_chain_kernel"}
+                "ffn_chain_fwd": "ffn_chain_kernel", "gemm_ln_bwd": "gemm_nt_dma_kernel<6>",
+                "gemm_res_ln": "gemm_nt_dma_kernel<7>"}
 HBM_ACHIEVABLE_GBS = 6290.0   # float4 streaming copy on this part (measured ceiling; the datasheet peak is 8000)
 
 
