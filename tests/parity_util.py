@@ -13,12 +13,15 @@ noise in ALL its components -- hence the row RMS; the tensor RMS floors it for r
 `margin(got, ref)` is the smallest ATOL_RMS that makes the bound hold for a tensor pair; tests print it and assert
 it against the class limit (limits are at most twice the largest value measured on MI355X over the test cases of
 that class).
+The gradients of to_q / to_k are the least well conditioned quantities here (small differences of large terms: their
+norm is 50 times below to_v's): flipping the bf16 rounding of one LayerNorm output element in 70,000 moves their
+largest element-wise margin by as much as the limit allows, while their relative L2 error stays near 1e-2.
 """
 import torch
 
 RTOL = 1e-2
 ATOL_RMS_ACT = 4e-2      # logits, encodings, attention / layer outputs   (largest measured: 2.1e-2)
-ATOL_RMS_GRAD = 1.6e-1   # parameter and input gradients                  (largest measured: 8.2e-2)
+ATOL_RMS_GRAD = 1.6e-1   # parameter and input gradients                  (largest measured: 8.6e-2)
 
 
 def _d(t):
