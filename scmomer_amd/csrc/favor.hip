@@ -390,7 +390,10 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
 // stab (forward keys only, else null): the per-(b,h, chunk, wave) running maxima of the raw key scores, nstab of
 // them in all.  The partials were taken against the per-feature constant b_m = |w_m|^2 / 2; here they are brought
 // to the reference's stabiliser, the global max: factor exp(b_m - c max(stab)) per feature.
-__global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __restrict__ part, int nchunks,
+// NCH > 0: the number of chunks as a compile-time constant (the usual 8): every load of the workgroup is then
+// issued before the first sum needs one, instead of one round trip per chunk; the sums run in the same order.
+template <int NCH>
+__global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __restrict__ part, int nchunks_rt,
                                                                const float* __restrict__ stab, int nstab,
                                                                const bf16* __restrict__ omega_b,
                                                                float* __restrict__ gmax_out /*sums [bh][80]*/,
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
   __shared__ float colp[4][DH];
   __shared__ float zl[32];
   const int tid = threadIdx.x, bh = blockIdx.x, tile = blockIdx.y;
+  const int nchunks = NCH > 0 ? NCH : nchunks_rt;
   const float* base = part + (long)bh * nchunks * CTX_PART;
   __shared__ float wmaxs[4];
   __shared__ float fscale[32];
@@ -411,24 +415,42 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
   float acc8[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
-  for (int c = 0; c < nchunks; ++c) {   // 8 independent loads in flight per chunk
-    const float* rec = base + (long)c * CTX_PART + (32 * tile + q) * DH + d;
+  if (NCH > 0) {
+    float v[NCH > 0 ? NCH : 1][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc8[i] += rec[4 * i * DH];
+    for (int c = 0; c < NCH; ++c) {
+      const float* rec = base + (long)c * CTX_PART + (32 * tile + q) * DH + d;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[c][i] = rec[4 * i * DH];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc8[i] += v[c][i];
+  } else {
+    for (int c = 0; c < nchunks; ++c) {   // 8 independent loads in flight per chunk
+      const float* rec = base + (long)c * CTX_PART + (32 * tile + q) * DH + d;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc8[i] += rec[4 * i * DH];
+    }
   }
   float m = -INFINITY;
   if (stab)
+#pragma unroll 8
     for (int i = tid; i < nstab; i += 256) m = fmaxf(m, stab[i]);
   if (tid < DH) {
     float s = 0.f;
+#pragma unroll
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NF * DH + tid];   // row of the ones feature
     ysum[tid] = s;
   } else if (tid == 64) {
     float s = 0.f;
+#pragma unroll
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + NF];    // z slot of the ones feature
     wsum = s;
   } else if (tid >= 128 && tid < 160) {
     float s = 0.f;
+#pragma unroll
     for (int c = 0; c < nchunks; ++c) s += base[(long)c * CTX_PART + NFP * DH + 32 * tile + (tid - 128)];
     zraw[tid - 128] = s;
   }
@@ -928,8 +950,12 @@ hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, 
   float* zz = M32 + (long)BH * NFP * DH;
   float* colpart = zz + (long)BH * NFP;
   Traced tr(K_CTX_FINALIZE, 0, s);
-  hipLaunchKernelGGL(favor_ctx_reduce_kernel, dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
-                     omega_b, sums, M32, zz, colpart);
+  if (nchunks == 8)
+    hipLaunchKernelGGL((favor_ctx_reduce_kernel<8>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+                       omega_b, sums, M32, zz, colpart);
+  else
+    hipLaunchKernelGGL((favor_ctx_reduce_kernel<0>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+                       omega_b, sums, M32, zz, colpart);
   hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH, NFT), dim3(256), 0, s, M32, zz, colpart, mode, sums_fwd,
                      (bf16*)Mb, zf, sums);
   return hipGetLastError();
