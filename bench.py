@@ -522,7 +522,14 @@ def main():
         traffic, traffic_src = measured_traffic(dominant)
         mfma_util, valu_busy, util_src = measured_utilisation(dominant)
         step_bytes = sum(v[3] for v in trace.values()) / traced_steps
-        roof = {"bound": bound, "kernel": dominant,
+        # `bound` names the roof the kernel's arithmetic intensity puts it under; `limiter` says what the counter
+        # passes show it waiting on (the attention passes sit under the HBM roof but are paced by vector-ALU issue)
+        limiter = None
+        if valu_busy is not None and mfma_util is not None:
+            limiter = (f"vector-ALU issue: vector ALU busy {valu_busy:.0%} of the kernel's cycles, matrix cores "
+                       f"{mfma_util:.0%} ({util_src})" if valu_busy >= 0.4 and valu_busy > mfma_util
+                       else f"memory streaming: vector ALU busy {valu_busy:.0%}, matrix cores {mfma_util:.0%} ({util_src})")
+        roof = {"bound": bound, "limiter": limiter, "kernel": dominant,
                 "achieved": tflops if bound == "mfma" else gbs,
                 "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
