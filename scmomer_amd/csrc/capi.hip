@@ -426,7 +426,7 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   // 3. key side: dk, dv
   ApplyArgs g{};
   g.x = cview(k); g.y = cview(v); g.omega_b = (const bf16*)omega_b; g.Mb = (const bf16*)dctx_bf16; g.zf = dz;
-  g.sums = dsums; g.out0 = oview(dk); g.out1 = oview(dv);
+  g.sums = dsums; g.colpart = favor_fin_colpart(fin, B * H); g.out0 = oview(dk); g.out1 = oview(dv);
   g.stab = sums + DH + 1; g.nstab = 1;   // the global key stabiliser, left there by the forward
   g.H = H; g.N = N;
   g.ksum_part = ws;  // the chunk partials in ws were consumed by the finalize step above

@@ -392,13 +392,18 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
 // to the reference's stabiliser, the global max: factor exp(b_m - c max(stab)) per feature.
 // NCH > 0: the number of chunks as a compile-time constant (the usual 8): every load of the workgroup is then
 // issued before the first sum needs one, instead of one round trip per chunk; the sums run in the same order.
-template <int NCH>
+// BWD (the backward's dC, dz; no stabiliser): the finalize step is done here as well -- it needs nothing from other
+// tiles: Mb = bf16(dC) and zf[m] = dz[m] - dC[m,:] . obar_fwd are written directly (M32 / zz are not), and the
+// consumer adds up the nine column partials itself.
+template <int NCH, bool BWD>
 __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __restrict__ part, int nchunks_rt,
                                                                const float* __restrict__ stab, int nstab,
                                                                const bf16* __restrict__ omega_b,
                                                                float* __restrict__ gmax_out /*sums [bh][80]*/,
                                                                float* __restrict__ M32, float* __restrict__ zz,
-                                                               float* __restrict__ colpart /*[bh][9][80]*/) {
+                                                               float* __restrict__ colpart /*[bh][9][80]*/,
+                                                               const float* __restrict__ sums_fwd, bf16* __restrict__ Mb,
+                                                               float* __restrict__ zf) {
   __shared__ float ysum[DH];
   __shared__ float wsum;
   __shared__ float colp[4][DH];
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
   // Everything this workgroup reads is independent of what it computes, so all loads are issued up front (the
   // chunk sums of its 32 x 64 context entries first) and the dependent steps follow after ONE round trip.
   const int d = tid & 63, q = tid >> 6;
+  const float ob = BWD ? sums_fwd[(long)bh * SUMS_STRIDE + d] : 0.f;   // forward obar[d]
   float acc8[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
@@ -477,14 +483,21 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
     const int mm = 32 * tile + tid;
     const float v = (mm < NF) ? fscale[tid] * zraw[tid] + KEPS * wsum : 0.f;
     zl[tid] = v;
-    zz[(long)bh * NFP + mm] = v;
+    if (!BWD) zz[(long)bh * NFP + mm] = v;
   }
+  if (BWD) __syncthreads();   // zl is read below
   float csum = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = 32 * tile + q + 4 * i;
     const float v = (m < NF) ? fscale[q + 4 * i] * acc8[i] + KEPS * ysum[d] : 0.f;
-    M32[((long)bh * NFP + m) * DH + d] = v;
+    if (BWD) {
+      Mb[((long)bh * NFP + m) * DH + d] = (bf16)v;
+      const float dot = wave_sum(v * ob);  // the 64 lanes of this wave hold row m
+      if (d == 0) zf[(long)bh * NFP + m] = (m < NF) ? zl[q + 4 * i] - dot : 0.f;
+    } else {
+      M32[((long)bh * NFP + m) * DH + d] = v;
+    }
     csum += v;
   }
   colp[q][d] = csum;
@@ -629,7 +642,16 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
   load_image(omg, a.omega_b, tid, 512);
   load_image(mim, a.Mb + (long)bh * NFP * DH, tid, 512);
   for (int i = tid; i < NFP; i += 512) zv[i] = a.zf[(long)bh * NFP + i];
-  if (tid < SUMS_STRIDE) sm[tid] = a.sums[(long)bh * SUMS_STRIDE + tid];
+  if (tid < SUMS_STRIDE) {
+    if (MODE == 2 && a.colpart) {   // colsum(dC) = the nine tile partials of the backward context reduction, in order
+      float cs = 0.f;
+#pragma unroll
+      for (int t = 0; t < NFT; ++t) cs += a.colpart[((long)bh * NFT + t) * SUMS_STRIDE + tid];
+      sm[tid] = tid < DH ? cs : 0.f;
+    } else {
+      sm[tid] = a.sums[(long)bh * SUMS_STRIDE + tid];
+    }
+  }
   float gstab = 0.f;
   if (MODE == 2) gstab = reduce_partial_max(a.stab, a.nstab);
   __syncthreads();
@@ -950,16 +972,27 @@ hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, 
   float* zz = M32 + (long)BH * NFP * DH;
   float* colpart = zz + (long)BH * NFP;
   Traced tr(K_CTX_FINALIZE, 0, s);
+  if (mode == 1) {   // backward: one launch (the consumer sums the column partials, favor_fin_colpart)
+    if (nchunks == 8)
+      hipLaunchKernelGGL((favor_ctx_reduce_kernel<8, true>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+                         omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
+    else
+      hipLaunchKernelGGL((favor_ctx_reduce_kernel<0, true>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+                         omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
+    return hipGetLastError();
+  }
   if (nchunks == 8)
-    hipLaunchKernelGGL((favor_ctx_reduce_kernel<8>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
-                       omega_b, sums, M32, zz, colpart);
+    hipLaunchKernelGGL((favor_ctx_reduce_kernel<8, false>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+                       omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
   else
-    hipLaunchKernelGGL((favor_ctx_reduce_kernel<0>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
-                       omega_b, sums, M32, zz, colpart);
+    hipLaunchKernelGGL((favor_ctx_reduce_kernel<0, false>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+                       omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
   hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH, NFT), dim3(256), 0, s, M32, zz, colpart, mode, sums_fwd,
                      (bf16*)Mb, zf, sums);
   return hipGetLastError();
 }
+
+float* favor_fin_colpart(float* scratch, int BH) { return scratch + (long)BH * NFP * DH + (long)BH * NFP; }
 
 size_t favor_apply_lds() { return APPLY_LDS; }
 

@@ -65,6 +65,7 @@ struct ApplyArgs {
   const bf16* Mb;          // [bh][288][64]  MODE 0,1: centred C ; MODE 2: dC
   const float* zf;         // [bh][288]      MODE 0,1: z ; MODE 2: dz
   const float* sums;       // [bh][80]       MODE 0: obar[64], sum(z) ; MODE 2: colsum(dC)
+  const float* colpart;    // MODE 2, optional: [bh][9][80] tile partials whose sum is colsum(dC) (then sums is not read)
   const float* stab;       // MODE 1: rowmax [B*H*N] ; MODE 2: kmax partials
   int nstab;
   const float* den_in;     // MODE 1
@@ -193,6 +194,7 @@ hipError_t favor_kfix(const float* part_val, const long long* part_key, int nsta
                       const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s);
 hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s);
 constexpr int CTX_FIN_SCRATCH = NFP * DH + NFP + NFT * SUMS_STRIDE;  // floats per (b,h) of finalize scratch
+float* favor_fin_colpart(float* scratch, int BH);   // where favor_ctx_finalize leaves the column partials
 hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int nstab,
                               const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s);
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s);
