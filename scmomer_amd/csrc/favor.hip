@@ -33,6 +33,7 @@ constexpr int STAGE_PITCH = 68;                     // floats per staged output 
 // favor_apply LDS: Omega and context images, z, sums, 8 output stages
 constexpr int APPLY_LDS_MAIN = 2 * NFP * 128 + (NFP + SUMS_STRIDE) * 4 + 8 * 32 * STAGE_PITCH * 4;
 constexpr int APPLY_LDS = APPLY_LDS_MAIN;
+constexpr int APPLY_LDS_DQ = 2 * NFP * 128 + (NFP + SUMS_STRIDE) * 4 + 12 * 16 * STAGE_PITCH * 4;   // 12 waves, half-tile stages
 
 SCM_DEV void load_image(char* img, const bf16* __restrict__ src /*[288][64]*/, int tid, int nthreads) {
   for (int c = tid; c < NFP * 8; c += nthreads) {
@@ -578,6 +579,23 @@ SCM_DEV void stage_rows(float* stage, const f32x16 (&y)[2], float scale, const f
     }
 }
 
+// The same for one half of the tile (tokens 16 pass .. 16 pass + 15) into a 16-row stage: the 12-wave form of the dq
+// pass has room for half a tile per wave only.
+SCM_DEV void stage_rows_half(float* stage, const f32x16 (&y)[2], float scale, int pass) {
+  const int l = lane_id(), tok = l & 31, half = l >> 5;
+  if ((tok >> 4) != pass) return;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * dt + 8 * g + 4 * half;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = y[dt][4 * g + i] * scale;
+      *(f32x4*)(stage + (tok & 15) * STAGE_PITCH + d) = v;
+    }
+}
+
 // coalesced write-back of a staged [32][64] f32 tile as bf16; optional rank-1 correction
 // out[row][d] = stage[row][d] + stage[row][64] * corr_scale * xrow[d]
 // and, with omg != null, + stage[row][65] * Omega[(int)stage[row][66]][d] (Omega from its LDS image)
@@ -592,13 +610,15 @@ SCM_DEV void load_x_rows(bf16x8 (&xr)[4], brsrc rxx, long xsn, int n0, int n_hi)
   }
 }
 
+// I0, NI: the groups of 8 rows written (all four, or the two of a half-tile stage whose row 0 is tile row 8 I0)
+template <int I0 = 0, int NI = 4>
 SCM_DEV void store_rows(const float* stage, brsrc ro, long osn, const bf16x8* xr /*4 rows or null*/, float corr_scale,
                         int n0, int n_hi, const char* omg = nullptr, const float* colbias = nullptr) {
   const int l = lane_id();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * i + (l >> 3), ch = l & 7;
-    const int n = n0 + row;
+  for (int i = I0; i < I0 + NI; ++i) {
+    const int trow = 8 * i + (l >> 3), row = trow - 8 * I0, ch = l & 7;
+    const int n = n0 + trow;
     const bool ok = n < n_hi;     // rows past the chunk: stores are dropped (no branches)
     const f32x4 a = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch);
     const f32x4 b = *(const f32x4*)(stage + row * STAGE_PITCH + 8 * ch + 4);
@@ -626,22 +646,27 @@ SCM_DEV void store_rows(const float* stage, brsrc ro, long osn, const bf16x8* xr
   }
 }
 
+// The dq pass (MODE 1) needs 166 registers, which leaves room for three waves per SIMD: it runs 12 waves per
+// workgroup, each with a half-tile output stage (written back in two passes); the other passes run 8.
 template <int MODE>
-__global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
+__global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(ApplyArgs a) {
+  constexpr int NW = MODE == 1 ? 12 : 8;              // waves per workgroup
+  constexpr int NTH = 64 * NW, TRIP = 32 * NW;        // threads; tokens per trip of the workgroup
+  constexpr int STAGE_ROWS = MODE == 1 ? 16 : 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* omg = smem;                                   // Omega image
   char* mim = smem + NFP * 128;                       // C or dC image
   float* zv = (float*)(smem + 2 * NFP * 128);         // [288]
   float* sm = zv + NFP;                               // [80]
-  float* stage_all = sm + SUMS_STRIDE;                // 8 x [32][68]
+  float* stage_all = sm + SUMS_STRIDE;                // NW x [STAGE_ROWS][68]
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int n_lo = blockIdx.x * a.chunk_len, n_hi = min(a.N, n_lo + a.chunk_len);
-  float* stage = stage_all + w * 32 * STAGE_PITCH;
+  float* stage = stage_all + w * STAGE_ROWS * STAGE_PITCH;
 
-  load_image(omg, a.omega_b, tid, 512);
-  load_image(mim, a.Mb + (long)bh * NFP * DH, tid, 512);
-  for (int i = tid; i < NFP; i += 512) zv[i] = a.zf[(long)bh * NFP + i];
+  load_image(omg, a.omega_b, tid, NTH);
+  load_image(mim, a.Mb + (long)bh * NFP * DH, tid, NTH);
+  for (int i = tid; i < NFP; i += NTH) zv[i] = a.zf[(long)bh * NFP + i];
   if (tid < SUMS_STRIDE) {
     if (MODE == 2 && a.colpart) {   // colsum(dC) = the nine tile partials of the backward context reduction, in order
       float cs = 0.f;
@@ -707,7 +732,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
   // everything), on the back edge they are followed by the previous tile's stores -- and the merged wait made every
   // tile wait for the stores of the one before.
   wait_vmcnt<0>();
-  for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += 256) {
+  for (int n0 = n_lo + 32 * w; n0 < n_hi; n0 += TRIP) {
     const int n = n0 + (l & 31);
     const bool valid = n < n_hi;
     bf16x8 nxf[4], nyf[4], ny2f[4];   // the next tile's fragments, fetched before this tile's stores
@@ -755,7 +780,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       const float inv = 1.f / den;
       // the context image is centred (its feature-sum is zero, so the eps term vanishes):
       // Y / den = o - obar
-      fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
+      fetch(n0 + TRIP, nxf, nyf, ny2f, nden, nrmx);
       stage_rows(stage, Y, inv, nullptr, 0.f);
       __builtin_amdgcn_wave_barrier();
       if (has_out1) store_rows(stage, ro1, a.out1.sn, nullptr, 0.f, n0, n_hi);
@@ -836,17 +861,22 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       jstar = min(jstar, __shfl_xor(jstar, 32));
       bf16x8 xr[4];
       load_x_rows(xr, rx, a.x.sn, n0, n_hi);
-      fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
-      stage_rows(stage, Y, CNORM, nullptr, 0.f);
-      if (l < 32) {
-        stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
-        // stabiliser gradient: rowmax = S[n, j*]  =>  dq += -c * (sum(dA) - dA[j*]) * Omega[j*]
-        stage[(l & 31) * STAGE_PITCH + 65] = (jstar < NF) ? CNORM * stabc : 0.f;
-        ((int*)stage)[(l & 31) * STAGE_PITCH + 66] = (jstar < NF) ? jstar : 0;
-      }
-      __builtin_amdgcn_wave_barrier();
-      store_rows(stage, ro0, a.out0.sn, xr, 2.f * HALF_C2, n0, n_hi, omg);
-      __builtin_amdgcn_wave_barrier();
+      fetch(n0 + TRIP, nxf, nyf, ny2f, nden, nrmx);
+      auto half_tile = [&](auto pass_c) {   // tokens 16 pass .. 16 pass + 15 of the tile through the 16-row stage
+        constexpr int PASS = decltype(pass_c)::value;
+        stage_rows_half(stage, Y, CNORM, PASS);
+        if (l < 32 && (l >> 4) == PASS) {
+          stage[(l & 15) * STAGE_PITCH + 64] = ddiag;
+          // stabiliser gradient: rowmax = S[n, j*]  =>  dq += -c * (sum(dA) - dA[j*]) * Omega[j*]
+          stage[(l & 15) * STAGE_PITCH + 65] = (jstar < NF) ? CNORM * stabc : 0.f;
+          ((int*)stage)[(l & 15) * STAGE_PITCH + 66] = (jstar < NF) ? jstar : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_rows<2 * PASS, 2>(stage, ro0, a.out0.sn, xr, 2.f * HALF_C2, n0, n_hi, omg);
+        __builtin_amdgcn_wave_barrier();
+      };
+      half_tile(std::integral_constant<int, 0>{});
+      half_tile(std::integral_constant<int, 1>{});
       if (valid && l < 32) a.dden_out[srow + n] = dden;
     }
 
@@ -900,7 +930,7 @@ __global__ __launch_bounds__(512) void favor_apply_kernel(ApplyArgs a) {
       if (valid && l < 32) ksum -= ddiag;
       bf16x8 xr[4];
       load_x_rows(xr, rx, a.x.sn, n0, n_hi);
-      fetch(n0 + 256, nxf, nyf, ny2f, nden, nrmx);
+      fetch(n0 + TRIP, nxf, nyf, ny2f, nden, nrmx);
       // dk first (it consumes the x rows), then dv = E dC + eps * colsum(dC)
       stage_rows(stage, Yk, CNORM, nullptr, 0.f);
       if (l < 32) stage[(l & 31) * STAGE_PITCH + 64] = ddiag;
@@ -998,7 +1028,7 @@ size_t favor_apply_lds() { return APPLY_LDS; }
 
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s) {
   a.chunk_len = round_up((a.N + nchunks - 1) / nchunks, 32);
-  const size_t lds = favor_apply_lds();
+  const size_t lds = mode == 1 ? (size_t)APPLY_LDS_DQ : favor_apply_lds();
   static std::atomic<unsigned long long> ready[3];
   const void* kfn = mode == 0 ? (const void*)favor_apply_kernel<0>
                               : (mode == 1 ? (const void*)favor_apply_kernel<1> : (const void*)favor_apply_kernel<2>);
@@ -1013,7 +1043,7 @@ hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s)
             // dq out, 3 row scalars; mode 2 k, v in, dk, dv out
             th * (mode == 0 ? (a.out1.p ? 392.0 : 256.0) : (mode == 1 ? 524.0 : 512.0)));
   if (mode == 0) hipLaunchKernelGGL((favor_apply_kernel<0>), grid, dim3(512), lds, s, a);
-  else if (mode == 1) hipLaunchKernelGGL((favor_apply_kernel<1>), grid, dim3(512), lds, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((favor_apply_kernel<1>), grid, dim3(768), lds, s, a);
   else hipLaunchKernelGGL((favor_apply_kernel<2>), grid, dim3(512), lds, s, a);
   return hipGetLastError();
 }
