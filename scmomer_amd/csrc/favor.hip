@@ -186,14 +186,21 @@ __global__ __launch_bounds__(256) void favor_kfix_kernel(const float* __restrict
 constexpr int CTX_TILE = 64;
 constexpr int CTX_BUF = 2 * CTX_TILE * 128 + 2 * CTX_TILE * 4;  // x image, y image, off[], wgt[]
 
+// 12 waves: nine compute waves (one per tile of 32 features) and three loader waves that bring the next token tile
+// in, normalise it and write its LDS images while the compute waves work -- three waves on every SIMD, and the
+// compute waves carry no loading work.
+constexpr int CTX_LOADERS = 192;                        // threads of the loader waves
+constexpr int CTX_LD_PER = (CTX_TILE * 8 + CTX_LOADERS - 1) / CTX_LOADERS;   // (row, 16-byte chunk) pairs per loader thread: 3
 template <int MODE>
-__global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
+__global__ __launch_bounds__(768) void favor_ctx_kernel(CtxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = l >> 5;
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, half = l >> 5;
+  const bool compute = __builtin_amdgcn_readfirstlane(wv) < NFT;   // wave-uniform
+  const int w = compute ? wv : NFT - 1;                              // feature tile (loader waves: any valid one)
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int n_lo = blockIdx.x * a.chunk_len, n_hi = min(a.N, n_lo + a.chunk_len);
-  const bool loader = tid < 512;
-  const int lrow = tid >> 3, lch = tid & 7;
+  const bool loader = !compute;
+  const int lt = tid - 64 * NFT;                                     // loader thread number
 
   // MODE 0 (keys): the reference stabilises with ONE max over the whole [B,H,N,M] score tensor
   // (performer_pytorch.py:89-90).  No separate pass computes it.  Every feature is exponentiated against its own
@@ -236,39 +243,52 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
   const bf16* yb = a.y.p + b * a.y.sb + h * a.y.sh;
   const long srow = (long)bh * a.N;
 
-  bf16x8 xs_r, ys_r;
-  float st_r = 0.f, den_r = 1.f, w_r = 0.f;
-  bool val_r = false;
+  // loader thread lt handles the pairs (row, chunk) number lt, lt + 192, lt + 384 of the 64 x 8 of a tile: the eight
+  // lanes of a row stay together (192 is a multiple of 8), which the row's sum of squares relies on
+  bf16x8 xs_r[CTX_LD_PER], ys_r[CTX_LD_PER];
+  float st_r[CTX_LD_PER], den_r[CTX_LD_PER], w_r[CTX_LD_PER];
+  bool val_r[CTX_LD_PER];
+  const int lch = lt & 7;
   auto load_tile = [&](int n0) {
     if (!loader) return;
-    const int n = n0 + lrow;
-    val_r = n < n_hi;
-    xs_r = zero_frag(); ys_r = zero_frag(); st_r = 0.f; den_r = 1.f; w_r = 0.f;
-    if (val_r) {
-      xs_r = *(const bf16x8*)(xb + (long)n * a.x.sn + 8 * lch);
-      ys_r = *(const bf16x8*)(yb + (long)n * a.y.sn + 8 * lch);
-      if (MODE == 1) { st_r = a.stab[srow + n]; den_r = a.den[srow + n]; w_r = a.dden[srow + n]; }
+#pragma unroll
+    for (int k = 0; k < CTX_LD_PER; ++k) {
+      const int lrow = (lt >> 3) + (CTX_LOADERS / 8) * k;
+      const int n = n0 + lrow;
+      val_r[k] = lrow < CTX_TILE && n < n_hi;
+      xs_r[k] = zero_frag(); ys_r[k] = zero_frag(); st_r[k] = 0.f; den_r[k] = 1.f; w_r[k] = 0.f;
+      if (val_r[k]) {
+        xs_r[k] = *(const bf16x8*)(xb + (long)n * a.x.sn + 8 * lch);
+        ys_r[k] = *(const bf16x8*)(yb + (long)n * a.y.sn + 8 * lch);
+        if (MODE == 1) { st_r[k] = a.stab[srow + n]; den_r[k] = a.den[srow + n]; w_r[k] = a.dden[srow + n]; }
+      }
     }
   };
   auto write_tile = [&](char* buf) {
     if (!loader) return;
-    float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float v = (float)xs_r[j]; ss += v * v; }
-    ss += dpp_move<0xB1>(ss); ss += dpp_move<0x4E>(ss); ss += dpp_move<0x141>(ss);   // the 8 lanes of a row
-    bf16x8 yv = ys_r;
-    if (MODE == 1) {
-      const float inv = 1.f / den_r;
+    for (int k = 0; k < CTX_LD_PER; ++k) {
+      const int lrow = (lt >> 3) + (CTX_LOADERS / 8) * k;
+      float ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) yv[j] = (bf16)((float)ys_r[j] * inv);
-    }
-    *(bf16x8*)(buf + img_off(lrow, 8 * lch)) = xs_r;
-    *(bf16x8*)(buf + CTX_TILE * 128 + img_off(lrow, 8 * lch)) = yv;
-    if (lch == 0) {
-      const float stab = (MODE == 0) ? 0.f : st_r;   // MODE 0: the stabiliser is applied by the consuming wave
-      float* off = (float*)(buf + 2 * CTX_TILE * 128);
-      off[lrow] = val_r ? (HALF_C2 * ss + CNORM * stab) * LOG2E : INFINITY;
-      off[CTX_TILE + lrow] = (MODE == 1) ? w_r : (val_r ? 1.f : 0.f);
+      for (int j = 0; j < 8; ++j) { const float v = (float)xs_r[k][j]; ss += v * v; }
+      ss += dpp_move<0xB1>(ss); ss += dpp_move<0x4E>(ss); ss += dpp_move<0x141>(ss);   // the 8 lanes of a row
+      bf16x8 yv = ys_r[k];
+      if (MODE == 1) {
+        const float inv = 1.f / den_r[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yv[j] = (bf16)((float)ys_r[k][j] * inv);
+      }
+      if (lrow < CTX_TILE) {
+        *(bf16x8*)(buf + img_off(lrow, 8 * lch)) = xs_r[k];
+        *(bf16x8*)(buf + CTX_TILE * 128 + img_off(lrow, 8 * lch)) = yv;
+        if (lch == 0) {
+          const float stab = (MODE == 0) ? 0.f : st_r[k];   // MODE 0: the stabiliser is applied by the consuming wave
+          float* off = (float*)(buf + 2 * CTX_TILE * 128);
+          off[lrow] = val_r[k] ? (HALF_C2 * ss + CNORM * stab) * LOG2E : INFINITY;
+          off[CTX_TILE + lrow] = (MODE == 1) ? w_r[k] : (val_r[k] ? 1.f : 0.f);
+        }
+      }
     }
   };
 
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     const float* off = (const float*)(buf + 2 * CTX_TILE * 128);
     const float* wg = off + CTX_TILE;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < (compute ? 2 : 0); ++sub) {
       // S[token, feature] = x_tile (32x64) * Omega_w^T (64x32)
       f32x16 s;
 #pragma unroll
@@ -340,6 +360,7 @@ __global__ __launch_bounds__(576) void favor_ctx_kernel(CtxArgs a) {
     __syncthreads();
   }
 
+  if (!compute) return;     // the loader waves are done (no barrier follows)
   // The arg-max resolution below reads global memory: it comes BEFORE the partial record is stored (a load issued
   // after the stores would wait for them to retire).
   if (MODE == 0) {
@@ -989,9 +1010,9 @@ hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
   // bytes per (token, head): mode 0 reads k, v; mode 1 reads q, dout, the centred output and 3 f32 row scalars
   Traced tr(mode == 0 ? K_CTX_FWD : K_CTX_BWD, th * (mode == 0 ? 68096.0 : 34580.0), s, th * (mode == 0 ? 256.0 : 396.0));
   if (mode == 0)
-    hipLaunchKernelGGL((favor_ctx_kernel<0>), dim3(nchunks, B * a.H), dim3(576), lds, s, a);
+    hipLaunchKernelGGL((favor_ctx_kernel<0>), dim3(nchunks, B * a.H), dim3(768), lds, s, a);
   else
-    hipLaunchKernelGGL((favor_ctx_kernel<1>), dim3(nchunks, B * a.H), dim3(576), lds, s, a);
+    hipLaunchKernelGGL((favor_ctx_kernel<1>), dim3(nchunks, B * a.H), dim3(768), lds, s, a);
   return hipGetLastError();
 }
 
