@@ -206,16 +206,23 @@ typedef struct {
   int kmax_chunks; /* key-stabiliser partials per (b,h): 9 per chunk of the K'^T V pass */
   int ctx_chunks;  /* token chunks per (b,h) of the K'^T V pass (partials in ws) */
   int apply_chunks;/* token chunks per (b,h) of the output pass */
+  int group_cells; /* cells per key-stabiliser group: the key features of performer_pytorch.py:89-90 are stabilised by
+                    * ONE max over everything in a call, so a launch that batches several reference calls (the
+                    * micro-batches of one gradient-accumulation window, s1_pretrain_rna.py:294-305) must keep one max
+                    * per call: cells [g*group_cells, (g+1)*group_cells) share a stabiliser (the last group may be
+                    * smaller).  scm_favor_make_plan sets it to B (one call); the caller may lower it (1 .. B) */
 } scm_favor_plan;
-/* fills the chunk counts for the MI355X (256 CUs) */
+/* fills the chunk counts for the MI355X (256 CUs); group_cells = B */
 int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan /* host */);
 int64_t scm_favor_ws_floats(const scm_favor_plan* plan /* host */);
 /* out = attention output; out_centered = out - obar[b,h,:] where obar is the (k'-weighted) mean value vector
  * of the head: kept for the backward, whose denominator path needs it at full relative precision.
  * Saved state of one forward call (caller-allocated):
- *   ctx_bf16 [B*H,288,64] bf16 (centred K'^T V), z [B*H,288] f32, sums [B*H,80] f32 (obar, sum z, key stabiliser),
+ *   ctx_bf16 [B*H,288,64] bf16 (centred K'^T V), z [B*H,288] f32, sums [B*H,80] f32 (obar, sum z, key stabiliser of
+ *   the (b,h)'s group),
  *   rowmax [B*H*N] f32, den [B*H*N] f32,
- *   kmax [kmax_chunks*B*H] f32 (partial maxima; their max is the key stabiliser of performer_pytorch.py:90),
+ *   kmax [kmax_chunks*B*H] f32 (partial maxima; their max over a stabiliser group is the key stabiliser of
+ *   performer_pytorch.py:90),
  *   kmax_idx [kmax_chunks*B*H] i64 (where each partial maximum sits: (bh*N + n)*512 + feature).
  * When no backward follows, out_centered.p and rowmax / den (both) may be NULL: they are then not written
  * (a third less traffic in the output pass). */
@@ -223,7 +230,7 @@ int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
                   scm_view4 out, scm_view4 out_centered, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
                   int64_t* kmax_idx, float* ws, void* stream);
 /* Backward of the above: dq, dk, dv from dout, including the gradient that autograd routes through both
- * stabilisers (per-token argmax for queries, the single global argmax for keys).  `o_centered` is the
+ * stabilisers (per-token argmax for queries, the single argmax of each stabiliser group for keys).  `o_centered` is the
  * second forward output.
  * Scratch: dctx_bf16/dz/dsums shaped like ctx_bf16/z/sums, dden [B*H*N]. */
 int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, scm_view4 o_centered,
@@ -271,14 +278,20 @@ int scm_head_bwd(const float* dout, const float* denc, const float* out, const f
 int scm_s1_mask(const int64_t* tokens, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,
                 float replace_prob, int max_masked, int64_t pad_id, int64_t mask_id, int64_t* masked_input,
                 int64_t* labels, void* stream);
-/* loss_count[0] = mean over tokens with label != ignore_index of -log softmax(logits[t,:])[label[t]],
- * loss_count[1] = number of such tokens (f32).  logits f32 [T,C], C <= 8.  ws: scm_ce_ws_floats(T) floats. */
-int64_t scm_ce_ws_floats(int64_t T);
-int scm_ce_fwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, float* ws,
-               float* loss_count, void* stream);
-/* dlogits = d loss / d logits * dloss[0] (dloss: device scalar, the incoming gradient of the loss). */
-int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, const float* dloss,
-               const float* loss_count, float* dlogits, void* stream);
+/* The tokens form loss groups of group_tokens consecutive tokens (the last may be shorter; group_tokens <= 0 or
+ * >= T: one group).  One group = one call of the reference's loss: a launch that batches the micro-batches of a
+ * gradient-accumulation window (s1_pretrain_rna.py:294-305) keeps one mean per micro-batch.  For group g:
+ * loss_count[2g] = mean over its tokens with label != ignore_index of -log softmax(logits[t,:])[label[t]],
+ * loss_count[2g+1] = number of such tokens (f32).  logits f32 [T,C], C <= 8.
+ * ws: scm_ce_ws_floats(T, group_tokens) floats; loss_count: 2 * scm_ce_groups(T, group_tokens) floats. */
+int64_t scm_ce_ws_floats(int64_t T, int64_t group_tokens);
+int64_t scm_ce_groups(int64_t T, int64_t group_tokens);
+int scm_ce_fwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, int64_t group_tokens,
+               float* ws, float* loss_count, void* stream);
+/* dlogits[t,:] = d loss_g / d logits[t,:] * dloss[g] for the tokens t of group g (dloss: device vector with one
+ * incoming gradient per group). */
+int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, int64_t group_tokens,
+               const float* dloss, const float* loss_count, float* dlogits, void* stream);
 
 /* Accuracy of the S1 loop (s1_pretrain_rna.py:308-312): per cell b, counts[b] = {number of positions with
  * label != pad_id whose prediction 1 + argmax(logits[b,n,1:C-1]) equals the label, number of such positions}

@@ -21,7 +21,7 @@ class View4(C.Structure):
 class FavorPlan(C.Structure):
     """scm_favor_plan"""
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("kmax_chunks", C.c_int),
-                ("ctx_chunks", C.c_int), ("apply_chunks", C.c_int)]
+                ("ctx_chunks", C.c_int), ("apply_chunks", C.c_int), ("group_cells", C.c_int)]
 
 
 vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
@@ -88,14 +88,15 @@ SIGNATURES = {
     "scm_trace_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_int64)]),
     "scm_s1_mask": (i32, [vp, vp, vp, i32, i32, C.c_float, C.c_float, i32, i64, i64, vp, vp, vp]),
-    "scm_ce_ws_floats": (i64, [i64]),
+    "scm_ce_ws_floats": (i64, [i64, i64]),
+    "scm_ce_groups": (i64, [i64, i64]),
     "scm_s1_accuracy": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp]),
     "scm_bin_max_genes": (i32, []),
     "scm_bin_csr": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]),
     "scm_bin_dense": (i32, [vp, i64, i32, i32, vp, vp]),
     "scm_orthogonal_omega": (i32, [vp, vp, i32, i32, i32, vp, vp]),
-    "scm_ce_fwd": (i32, [vp, vp, i64, i32, i64, vp, vp, vp]),
-    "scm_ce_bwd": (i32, [vp, vp, i64, i32, i64, vp, vp, vp, vp]),
+    "scm_ce_fwd": (i32, [vp, vp, i64, i32, i64, i64, vp, vp, vp]),
+    "scm_ce_bwd": (i32, [vp, vp, i64, i32, i64, i64, vp, vp, vp, vp]),
     "scm_head_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
     "scm_head_bwd_ws_floats": (i64, [i64, i32, i32]),
     "scm_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

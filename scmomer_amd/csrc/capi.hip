@@ -340,6 +340,7 @@ int scm_favor_make_plan(int B, int H, int N, scm_favor_plan* plan) {
   const int bh = B * H;
   const int cus = 256;
   plan->B = B; plan->H = H; plan->N = N;
+  plan->group_cells = B;   // one key stabiliser over the whole call, as one reference call has
   // Both passes run one workgroup per CU at a time (LDS / register bound), so the launch is a whole number of
   // rounds of 256 workgroups: pick the number of token chunks per (b,h) so that the last round is nearly full.
   // Few, long chunks are preferred (every workgroup first loads 74 KB of images; every context chunk costs a
@@ -365,13 +366,14 @@ int64_t scm_favor_ws_floats(const scm_favor_plan* p) {
 
 static int plan_ok(const scm_favor_plan* p) {
   return p && p->B > 0 && p->H > 0 && p->N > 0 && p->kmax_chunks > 0 && p->ctx_chunks > 0 && p->apply_chunks > 0 &&
+         p->group_cells > 0 && p->group_cells <= p->B &&
          (int64_t)p->B * p->H <= 65535 && (int64_t)p->B * p->H * p->N < (1ll << 31);
 }
 
 int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view4 v, const void* omega_b,
                   scm_view4 out, scm_view4 out_centered, void* ctx_bf16, float* z, float* sums, float* rowmax, float* den, float* kmax,
                   int64_t* kmax_idx, float* ws, void* stream) {
-  SCM_REQ(plan_ok(plan), "scm_favor_fwd: bad plan");
+  SCM_REQ(plan_ok(plan), "scm_favor_fwd: bad plan (sizes > 0, 1 <= group_cells <= B)");
   SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(out) && (!out_centered.p || view_ok(out_centered)),
           "scm_favor_fwd: bad tensor view (null/unaligned)");
   SCM_REQ(omega_b && ctx_bf16 && z && sums && kmax && kmax_idx && ws, "scm_favor_fwd: null pointer");
@@ -387,8 +389,8 @@ int scm_favor_fwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(0, c, B, plan->ctx_chunks, s), "favor_ctx");
   float* fin = ws + (int64_t)B * H * plan->ctx_chunks * CTX_PART;
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 0, kmax, plan->kmax_chunks * B * H, (const bf16*)omega_b,
-                             nullptr, ctx_bf16, z,
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 0, kmax, plan->kmax_chunks, plan->group_cells * H,
+                             (const bf16*)omega_b, nullptr, ctx_bf16, z,
                              sums, fin, s),
           "favor_ctx_finalize");
   ApplyArgs a{};
@@ -403,7 +405,7 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
                   const void* omega_b, const void* ctx_bf16, const float* z, const float* sums, const float* rowmax,
                   const float* den, const float* kmax, const int64_t* kmax_idx, scm_view4 dq, scm_view4 dk,
                   scm_view4 dv, void* dctx_bf16, float* dz, float* dsums, float* dden, float* ws, void* stream) {
-  SCM_REQ(plan_ok(plan), "scm_favor_bwd: bad plan");
+  SCM_REQ(plan_ok(plan), "scm_favor_bwd: bad plan (sizes > 0, 1 <= group_cells <= B)");
   SCM_REQ(view_ok(q) && view_ok(k) && view_ok(v) && view_ok(o_centered) && view_ok(dout) && view_ok(dq) && view_ok(dk) &&
               view_ok(dv), "scm_favor_bwd: bad tensor view (null/unaligned)");
   SCM_REQ(omega_b && ctx_bf16 && z && sums && rowmax && den && kmax && kmax_idx && dctx_bf16 && dz && dsums &&
@@ -421,19 +423,19 @@ int scm_favor_bwd(const scm_favor_plan* plan, scm_view4 q, scm_view4 k, scm_view
   c.dden = dden; c.H = H; c.N = N; c.part = ws;
   SCM_HIP(favor_ctx(1, c, B, plan->ctx_chunks, s), "favor_ctx(dC)");
   float* fin = ws + (int64_t)B * H * plan->ctx_chunks * CTX_PART;
-  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 1, nullptr, 0, nullptr, sums, dctx_bf16, dz, dsums, fin, s),
+  SCM_HIP(favor_ctx_finalize(ws, plan->ctx_chunks, B * H, 1, nullptr, 0, 1, nullptr, sums, dctx_bf16, dz, dsums, fin, s),
           "favor_ctx_finalize(dC)");
   // 3. key side: dk, dv
   ApplyArgs g{};
   g.x = cview(k); g.y = cview(v); g.omega_b = (const bf16*)omega_b; g.Mb = (const bf16*)dctx_bf16; g.zf = dz;
   g.sums = dsums; g.colpart = favor_fin_colpart(fin, B * H); g.out0 = oview(dk); g.out1 = oview(dv);
-  g.stab = sums + DH + 1; g.nstab = 1;   // the global key stabiliser, left there by the forward
+  g.stab = sums + DH + 1; g.nstab = 1; g.stab_stride = SUMS_STRIDE;   // each (b,h)'s key stabiliser, left there by the forward
   g.H = H; g.N = N;
   g.ksum_part = ws;  // the chunk partials in ws were consumed by the finalize step above
   SCM_HIP(favor_apply(2, g, B, plan->apply_chunks, s), "favor_apply(dk,dv)");
   // 4. gradient through the global key stabiliser lands on one token
-  SCM_HIP(favor_kfix(kmax, (const long long*)kmax_idx, plan->kmax_chunks * B * H, ws, plan->apply_chunks * B * H, omega_b, oview(dk), H,
-                     N, s), "favor_kfix");
+  SCM_HIP(favor_kfix(kmax, (const long long*)kmax_idx, plan->kmax_chunks, ws, plan->apply_chunks, B * H,
+                     plan->group_cells * H, omega_b, oview(dk), H, N, s), "favor_kfix");
   return 0;
 }
 
@@ -482,21 +484,32 @@ int scm_s1_mask(const int64_t* tokens, const float* rand_pick, const float* rand
   return 0;
 }
 
-int64_t scm_ce_ws_floats(int64_t T) { return 2 * (int64_t)ce_blocks(T); }
+static int64_t ce_group_tokens(int64_t T, int64_t group_tokens) { return (group_tokens <= 0 || group_tokens > T) ? T : group_tokens; }
 
-int scm_ce_fwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, float* ws,
-               float* loss_count, void* stream) {
+int64_t scm_ce_ws_floats(int64_t T, int64_t group_tokens) {
+  if (T <= 0) return 0;
+  const int64_t gt = ce_group_tokens(T, group_tokens);
+  return 2 * (int64_t)ce_blocks(gt) * ce_groups(T, gt);
+}
+int64_t scm_ce_groups(int64_t T, int64_t group_tokens) { return T <= 0 ? 0 : ce_groups(T, ce_group_tokens(T, group_tokens)); }
+
+int scm_ce_fwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, int64_t group_tokens,
+               float* ws, float* loss_count, void* stream) {
   SCM_REQ(logits && labels && ws && loss_count, "scm_ce_fwd: null pointer");
   SCM_REQ(T > 0 && C > 0 && C <= 8, "scm_ce_fwd: need 1 <= C <= 8");
-  SCM_HIP(ce_fwd(logits, labels, T, C, ignore_index, ws, loss_count, (hipStream_t)stream), "scm_ce_fwd");
+  const int64_t gt = ce_group_tokens(T, group_tokens);
+  SCM_REQ(ce_groups(T, gt) <= 65535, "scm_ce_fwd: more than 65535 loss groups");
+  SCM_HIP(ce_fwd(logits, labels, T, C, ignore_index, gt, ws, loss_count, (hipStream_t)stream), "scm_ce_fwd");
   return 0;
 }
 
-int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, const float* dloss,
-               const float* loss_count, float* dlogits, void* stream) {
+int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int64_t ignore_index, int64_t group_tokens,
+               const float* dloss, const float* loss_count, float* dlogits, void* stream) {
   SCM_REQ(logits && labels && dloss && loss_count && dlogits, "scm_ce_bwd: null pointer");
   SCM_REQ(T > 0 && C > 0 && C <= 8, "scm_ce_bwd: need 1 <= C <= 8");
-  SCM_HIP(ce_bwd(logits, labels, T, C, ignore_index, dloss, loss_count, dlogits, (hipStream_t)stream), "scm_ce_bwd");
+  const int64_t gt = ce_group_tokens(T, group_tokens);
+  SCM_REQ(ce_groups(T, gt) <= 65535, "scm_ce_bwd: more than 65535 loss groups");
+  SCM_HIP(ce_bwd(logits, labels, T, C, ignore_index, gt, dloss, loss_count, dlogits, (hipStream_t)stream), "scm_ce_bwd");
   return 0;
 }
 

@@ -151,14 +151,22 @@ SCM_DEV void wave_argmax(float& v, long long& key) {
 
 // Gradient through the key stabiliser (torch.max over the whole tensor, performer_pytorch.py:90):
 // dk[b*,h*,n*,:] += -c * (sum over everything of E * dE') * Omega[j*,:] at the argmax element.
+// One workgroup per stabiliser group (group_bh consecutive (b,h) pairs: the cells that share one max); stab_per_bh
+// and sum_per_bh are the numbers of stabiliser partials and of E * dE' partials per (b,h).
 __global__ __launch_bounds__(256) void favor_kfix_kernel(const float* __restrict__ part_val,
-                                                         const long long* __restrict__ part_key, int nstab,
-                                                         const float* __restrict__ ksum_part, int nsum,
+                                                         const long long* __restrict__ part_key, int stab_per_bh,
+                                                         const float* __restrict__ ksum_part, int sum_per_bh,
+                                                         int BH, int group_bh,
                                                          const bf16* __restrict__ omega_b, TensorBHND_out dk, int H,
                                                          int N) {
   __shared__ float wtot[4], wmx[4];
   __shared__ long long wkey[4];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int bh0 = blockIdx.x * group_bh, nbh = min(group_bh, BH - bh0);
+  part_val += (long)bh0 * stab_per_bh;
+  part_key += (long)bh0 * stab_per_bh;
+  ksum_part += (long)bh0 * sum_per_bh;
+  const int nstab = nbh * stab_per_bh, nsum = nbh * sum_per_bh;
   float tot = 0.f;
   for (int i = tid; i < nsum; i += 256) tot += ksum_part[i];
   tot = wave_sum(tot);
@@ -409,9 +417,11 @@ __global__ __launch_bounds__(768) void favor_ctx_kernel(CtxArgs a) {
   if (l < 32) rec[NFP * DH + 32 * w + l] = zt;
 }
 
-// stab (forward keys only, else null): the per-(b,h, chunk, wave) running maxima of the raw key scores, nstab of
-// them in all.  The partials were taken against the per-feature constant b_m = |w_m|^2 / 2; here they are brought
-// to the reference's stabiliser, the global max: factor exp(b_m - c max(stab)) per feature.
+// stab (forward keys only, else null): the per-(b,h, chunk, wave) running maxima of the raw key scores, stab_per_bh
+// of them per (b,h).  The partials were taken against the per-feature constant b_m = |w_m|^2 / 2; here they are
+// brought to the reference's stabiliser, the max over the whole call -- or, when several calls of the reference
+// are batched into one launch, over the group_bh consecutive (b,h) pairs that formed one call: factor
+// exp(b_m - c max(stab of the group)) per feature.
 // NCH > 0: the number of chunks as a compile-time constant (the usual 8): every load of the workgroup is then
 // issued before the first sum needs one, instead of one round trip per chunk; the sums run in the same order.
 // BWD (the backward's dC, dz; no stabiliser): the finalize step is done here as well -- it needs nothing from other
@@ -419,7 +429,8 @@ __global__ __launch_bounds__(768) void favor_ctx_kernel(CtxArgs a) {
 // consumer adds up the nine column partials itself.
 template <int NCH, bool BWD>
 __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __restrict__ part, int nchunks_rt,
-                                                               const float* __restrict__ stab, int nstab,
+                                                               const float* __restrict__ stab, int stab_per_bh,
+                                                               int group_bh,
                                                                const bf16* __restrict__ omega_b,
                                                                float* __restrict__ gmax_out /*sums [bh][80]*/,
                                                                float* __restrict__ M32, float* __restrict__ zz,
@@ -463,9 +474,13 @@ __global__ __launch_bounds__(256) void favor_ctx_reduce_kernel(const float* __re
     }
   }
   float m = -INFINITY;
-  if (stab)
+  if (stab) {   // the partial maxima of every (b,h) of this stabiliser group
+    const int bh0 = bh / group_bh * group_bh;
+    const int nstab = min(group_bh, (int)gridDim.x - bh0) * stab_per_bh;
+    const float* sg = stab + (long)bh0 * stab_per_bh;
 #pragma unroll 8
-    for (int i = tid; i < nstab; i += 256) m = fmaxf(m, stab[i]);
+    for (int i = tid; i < nstab; i += 256) m = fmaxf(m, sg[i]);
+  }
   if (tid < DH) {
     float s = 0.f;
 #pragma unroll
@@ -699,7 +714,7 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
     }
   }
   float gstab = 0.f;
-  if (MODE == 2) gstab = reduce_partial_max(a.stab, a.nstab);
+  if (MODE == 2) gstab = reduce_partial_max(a.stab + (long)bh * a.stab_stride, a.nstab);
   __syncthreads();
   const float zsum = sm[DH];
 
@@ -993,11 +1008,12 @@ hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
-                      const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s) {
+hipError_t favor_kfix(const float* part_val, const long long* part_key, int stab_per_bh, const float* ksum_part,
+                      int sum_per_bh, int BH, int group_bh, const void* omega_b, TensorBHND_out dk, int H, int N,
+                      hipStream_t s) {
   Traced tr(K_KFIX, 0, s);
-  hipLaunchKernelGGL(favor_kfix_kernel, dim3(1), dim3(256), 0, s, part_val, part_key, nstab, ksum_part, nsum,
-                     (const bf16*)omega_b, dk, H, N);
+  hipLaunchKernelGGL(favor_kfix_kernel, dim3((BH + group_bh - 1) / group_bh), dim3(256), 0, s, part_val, part_key,
+                     stab_per_bh, ksum_part, sum_per_bh, BH, group_bh, (const bf16*)omega_b, dk, H, N);
   return hipGetLastError();
 }
 
@@ -1017,26 +1033,26 @@ hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s) {
 }
 
 // scratch: BH * (288*64 + 288 + 9*80) floats placed by the caller after the chunk partials
-hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int nstab,
-                              const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s) {
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int stab_per_bh,
+                              int group_bh, const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s) {
   float* M32 = scratch;
   float* zz = M32 + (long)BH * NFP * DH;
   float* colpart = zz + (long)BH * NFP;
   Traced tr(K_CTX_FINALIZE, 0, s);
   if (mode == 1) {   // backward: one launch (the consumer sums the column partials, favor_fin_colpart)
     if (nchunks == 8)
-      hipLaunchKernelGGL((favor_ctx_reduce_kernel<8, true>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+      hipLaunchKernelGGL((favor_ctx_reduce_kernel<8, true>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, stab_per_bh, group_bh,
                          omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
     else
-      hipLaunchKernelGGL((favor_ctx_reduce_kernel<0, true>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+      hipLaunchKernelGGL((favor_ctx_reduce_kernel<0, true>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, stab_per_bh, group_bh,
                          omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
     return hipGetLastError();
   }
   if (nchunks == 8)
-    hipLaunchKernelGGL((favor_ctx_reduce_kernel<8, false>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+    hipLaunchKernelGGL((favor_ctx_reduce_kernel<8, false>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, stab_per_bh, group_bh,
                        omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
   else
-    hipLaunchKernelGGL((favor_ctx_reduce_kernel<0, false>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, nstab,
+    hipLaunchKernelGGL((favor_ctx_reduce_kernel<0, false>), dim3(BH, NFT), dim3(256), 0, s, part, nchunks, stab, stab_per_bh, group_bh,
                        omega_b, sums, M32, zz, colpart, sums_fwd, (bf16*)Mb, zf);
   hipLaunchKernelGGL(favor_ctx_finalize_kernel, dim3(BH, NFT), dim3(256), 0, s, M32, zz, colpart, mode, sums_fwd,
                      (bf16*)Mb, zf, sums);

@@ -134,13 +134,16 @@ __global__ __launch_bounds__(1024) void s1_mask_kernel(const int64_t* __restrict
 // ------------------------------------------------------------------------------------------
 constexpr int CE_MAXC = 8;
 
-// partial[block] = { sum of -log softmax(logits)[label], number of counted tokens }
+// Tokens are split into loss groups of group_tokens consecutive tokens (the last one may be shorter): every group
+// has its own mean, as when each group is one call of the loss (one micro-batch of s1_pretrain_rna.py:297).
+// grid (blocks, groups): partial[group][block] = { sum of -log softmax(logits)[label], number of counted tokens }
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits,
                                                      const int64_t* __restrict__ labels, long T, int C,
-                                                     long long ignore, float* __restrict__ partial) {
+                                                     long long ignore, long group_tokens, float* __restrict__ partial) {
   __shared__ float rs[4], rc[4];
   float s = 0.f, cnt = 0.f;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < T; t += (long)gridDim.x * 256) {
+  const long t_lo = (long)blockIdx.y * group_tokens, t_hi = min(T, t_lo + group_tokens);
+  for (long t = t_lo + (long)blockIdx.x * 256 + threadIdx.x; t < t_hi; t += (long)gridDim.x * 256) {
     const long long lab = labels[t];
     if (lab == ignore) continue;
     float v[CE_MAXC];
@@ -165,29 +168,33 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   if ((threadIdx.x & 63) == 0) { rs[w] = s; rc[w] = cnt; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partial[2 * blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
-    partial[2 * blockIdx.x + 1] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+    float* p = partial + 2 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+    p[0] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    p[1] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
   }
 }
 
-// out[0] = loss = sum / count (nan when nothing is counted, as torch), out[1] = count
+// one workgroup per group: out[g][0] = loss = sum / count (nan when nothing is counted, as torch), out[g][1] = count
 __global__ __launch_bounds__(64) void ce_finalize_kernel(const float* __restrict__ partial, int nblocks,
                                                          float* __restrict__ out) {
   float s = 0.f, c = 0.f;
+  partial += 2 * (long)blockIdx.x * nblocks;
   for (int i = threadIdx.x; i < nblocks; i += 64) { s += partial[2 * i]; c += partial[2 * i + 1]; }
   s = wave_sum(s);
   c = wave_sum(c);
-  if (threadIdx.x == 0) { out[0] = s / c; out[1] = c; }
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = s / c; out[2 * blockIdx.x + 1] = c; }
 }
 
-// dlogits[t][c] = (softmax(logits[t])[c] - [c == label]) * dloss / count for counted tokens, else 0
+// dlogits[t][c] = (softmax(logits[t])[c] - [c == label]) * dloss[g] / count[g] for counted tokens of group g, else 0
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits,
                                                      const int64_t* __restrict__ labels, long T, int C,
-                                                     long long ignore, const float* __restrict__ dloss,
+                                                     long long ignore, long group_tokens,
+                                                     const float* __restrict__ dloss,
                                                      const float* __restrict__ loss_count,
                                                      float* __restrict__ dlogits) {
-  const float scale = dloss[0] / loss_count[1];
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < T; t += (long)gridDim.x * 256) {
+  const float scale = dloss[blockIdx.y] / loss_count[2 * blockIdx.y + 1];
+  const long t_lo = (long)blockIdx.y * group_tokens, t_hi = min(T, t_lo + group_tokens);
+  for (long t = t_lo + (long)blockIdx.x * 256 + threadIdx.x; t < t_hi; t += (long)gridDim.x * 256) {
     const long long lab = labels[t];
     float v[CE_MAXC];
     float m = -INFINITY;
@@ -277,19 +284,20 @@ hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand
   return hipGetLastError();
 }
 int ce_blocks(long T) { long b = (T + 255) / 256; return (int)(b < 256 ? (b < 1 ? 1 : b) : 256); }
-hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, float* partial,
-                  float* out, hipStream_t s) {
+int ce_groups(long T, long group_tokens) { return (int)((T + group_tokens - 1) / group_tokens); }
+hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, long group_tokens,
+                  float* partial, float* out, hipStream_t s) {
   Traced tr(K_CE, 0, s);
-  const int nb = ce_blocks(T);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, s, logits, labels, T, C, ignore, partial);
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, out);
+  const int nb = ce_blocks(group_tokens), ng = ce_groups(T, group_tokens);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb, ng), dim3(256), 0, s, logits, labels, T, C, ignore, group_tokens, partial);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(ng), dim3(64), 0, s, partial, nb, out);
   return hipGetLastError();
 }
-hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, const float* dloss,
-                  const float* loss_count, float* dlogits, hipStream_t s) {
+hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, long group_tokens,
+                  const float* dloss, const float* loss_count, float* dlogits, hipStream_t s) {
   Traced tr(K_CE, 0, s);
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(T)), dim3(256), 0, s, logits, labels, T, C, ignore, dloss,
-                     loss_count, dlogits);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(group_tokens), ce_groups(T, group_tokens)), dim3(256), 0, s, logits,
+                     labels, T, C, ignore, group_tokens, dloss, loss_count, dlogits);
   return hipGetLastError();
 }
 

@@ -66,8 +66,9 @@ struct ApplyArgs {
   const float* zf;         // [bh][288]      MODE 0,1: z ; MODE 2: dz
   const float* sums;       // [bh][80]       MODE 0: obar[64], sum(z) ; MODE 2: colsum(dC)
   const float* colpart;    // MODE 2, optional: [bh][9][80] tile partials whose sum is colsum(dC) (then sums is not read)
-  const float* stab;       // MODE 1: rowmax [B*H*N] ; MODE 2: kmax partials
-  int nstab;
+  const float* stab;       // MODE 1: rowmax [B*H*N] ; MODE 2: key stabiliser partials of (b,h) at stab + bh * stab_stride
+  int nstab;               // MODE 2: partials per (b,h)
+  long stab_stride;
   const float* den_in;     // MODE 1
   TensorBHND_out out0;     // MODE 0: o ; MODE 1: dq ; MODE 2: dk
   TensorBHND_out out1;     // MODE 0: o - obar ; MODE 2: dv
@@ -173,10 +174,11 @@ hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand
                    float replace_prob, int max_masked, long long pad_id, long long mask_id, int64_t* masked,
                    int64_t* labels, hipStream_t s);
 int ce_blocks(long T);
-hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, float* partial,
-                  float* out, hipStream_t s);
-hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, const float* dloss,
-                  const float* loss_count, float* dlogits, hipStream_t s);
+int ce_groups(long T, long group_tokens);
+hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, long group_tokens,
+                  float* partial, float* out, hipStream_t s);
+hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, long group_tokens,
+                  const float* dloss, const float* loss_count, float* dlogits, hipStream_t s);
 hipError_t s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, long long pad_id, float* ratio,
                        int* counts, int* arrivals, hipStream_t s);
 
@@ -190,13 +192,14 @@ hipError_t orthogonal_omega(const float* gauss_blocks, const float* gauss_mult, 
 
 // favor.hip
 hipError_t favor_prep_omega(const float* omega, void* out, hipStream_t s);
-hipError_t favor_kfix(const float* part_val, const long long* part_key, int nstab, const float* ksum_part, int nsum,
-                      const void* omega_b, TensorBHND_out dk, int H, int N, hipStream_t s);
+hipError_t favor_kfix(const float* part_val, const long long* part_key, int stab_per_bh, const float* ksum_part,
+                      int sum_per_bh, int BH, int group_bh, const void* omega_b, TensorBHND_out dk, int H, int N,
+                      hipStream_t s);
 hipError_t favor_ctx(int mode, CtxArgs a, int B, int nchunks, hipStream_t s);
 constexpr int CTX_FIN_SCRATCH = NFP * DH + NFP + NFT * SUMS_STRIDE;  // floats per (b,h) of finalize scratch
 float* favor_fin_colpart(float* scratch, int BH);   // where favor_ctx_finalize leaves the column partials
-hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int nstab,
-                              const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s);
+hipError_t favor_ctx_finalize(const float* part, int nchunks, int BH, int mode, const float* stab, int stab_per_bh,
+                              int group_bh, const bf16* omega_b, const float* sums_fwd, void* Mb, float* zf, float* sums, float* scratch, hipStream_t s);
 hipError_t favor_apply(int mode, ApplyArgs a, int B, int nchunks, hipStream_t s);
 
 

@@ -357,18 +357,28 @@ class FavorSaved:
     kmax_idx: torch.Tensor  # their positions
 
 
-def make_plan(b: int, h: int, n: int) -> FavorPlan:
+def make_plan(b: int, h: int, n: int, group_cells: Optional[int] = None) -> FavorPlan:
+    """group_cells: cells per key-stabiliser group (None: the whole batch is one group, i.e. one reference call)"""
     plan = FavorPlan()
     check(lib.scm_favor_make_plan(b, h, n, C.byref(plan)), "scm_favor_make_plan")
+    if group_cells is not None and group_cells != b:
+        if not 1 <= group_cells <= b:
+            raise ValueError(f"group_cells must be in 1..{b}, got {group_cells}")
+        # the context pass splits the tokens of a (cell, head) exactly as a call over one group alone would: every
+        # cell's context sums then add up in the same order, and its attention output carries the same bits
+        alone = FavorPlan()
+        check(lib.scm_favor_make_plan(group_cells, h, n, C.byref(alone)), "scm_favor_make_plan")
+        plan.ctx_chunks, plan.kmax_chunks = alone.ctx_chunks, alone.kmax_chunks
+        plan.group_cells = group_cells
     return plan
 
 
-def favor_fwd(q, k, v, omega_b, out, out_centered) -> FavorSaved:
+def favor_fwd(q, k, v, omega_b, out, out_centered, group_cells: Optional[int] = None) -> FavorSaved:
     """q,k,v,out,out_centered: bf16 [B,H,N,64] views (any b/h/n strides).  out_centered=None: no backward will
-    follow; the centred output and the per-token statistics are not written."""
+    follow; the centred output and the per-token statistics are not written.  group_cells: see make_plan."""
     b, h, n, _ = q.shape
     dev = q.device
-    plan = make_plan(b, h, n)
+    plan = make_plan(b, h, n, min(group_cells, b) if group_cells else None)
     bh = b * h
     tape = out_centered is not None
     ctx = torch.empty((bh, NB_FEATURES_PAD, DIM_HEAD), dtype=BF16, device=dev)
@@ -492,24 +502,29 @@ def s1_mask(tokens: torch.Tensor, rand_pick: torch.Tensor, rand_replace: torch.T
     return masked, labels
 
 
-def ce_fwd(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int) -> torch.Tensor:
-    """-> f32 [2] = (mean loss over counted tokens, number of counted tokens)"""
+def ce_fwd(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int, group_tokens: int = 0) -> torch.Tensor:
+    """-> f32 [G, 2] = per loss group (mean loss over its counted tokens, number of counted tokens); the groups are
+    runs of group_tokens consecutive tokens (0: one group over everything)"""
     _req(logits, F32, "logits")
     _req(labels, torch.int64, "labels")
     c = logits.shape[-1]
     t = logits.numel() // c
-    ws = torch.empty(lib.scm_ce_ws_floats(t), dtype=F32, device=logits.device)
-    out = torch.empty(2, dtype=F32, device=logits.device)
-    check(lib.scm_ce_fwd(_p(logits), _p(labels), t, c, ignore_index, _p(ws), _p(out), _stream()), "scm_ce_fwd")
+    ws = torch.empty(lib.scm_ce_ws_floats(t, group_tokens), dtype=F32, device=logits.device)
+    out = torch.empty((lib.scm_ce_groups(t, group_tokens), 2), dtype=F32, device=logits.device)
+    check(lib.scm_ce_fwd(_p(logits), _p(labels), t, c, ignore_index, group_tokens, _p(ws), _p(out), _stream()),
+          "scm_ce_fwd")
     return out
 
 
-def ce_bwd(logits, labels, ignore_index: int, dloss: torch.Tensor, loss_count: torch.Tensor) -> torch.Tensor:
+def ce_bwd(logits, labels, ignore_index: int, dloss: torch.Tensor, loss_count: torch.Tensor,
+           group_tokens: int = 0) -> torch.Tensor:
+    """dloss: f32 [G], the incoming gradient of each group's loss"""
     c = logits.shape[-1]
     t = logits.numel() // c
+    assert dloss.numel() == loss_count.shape[0] == lib.scm_ce_groups(t, group_tokens)
     dlogits = torch.empty_like(logits)
-    check(lib.scm_ce_bwd(_p(logits), _p(labels), t, c, ignore_index, _p(dloss), _p(loss_count), _p(dlogits),
-                         _stream()), "scm_ce_bwd")
+    check(lib.scm_ce_bwd(_p(logits), _p(labels), t, c, ignore_index, group_tokens, _p(dloss), _p(loss_count),
+                         _p(dlogits), _stream()), "scm_ce_bwd")
     return dlogits
 
 

@@ -381,6 +381,11 @@ class Performer(nn.Module):
         # here: under the reference's DistributedDataParallel the buffer broadcast at every forward does that
         # (s1_pretrain_rna.py:242), so every replica keeps rank 0's draw.
         self.redraw_sync = None
+        # None: the key features of a forward are stabilised by ONE max over the whole batch, as in the reference
+        # (performer_pytorch.py:89-90).  An integer g: the batch is g-cell micro-batches stacked along dim 0 (a driver
+        # running several of the reference's forward calls as one launch chain); every run of g cells keeps its own
+        # max, so each micro-batch gets exactly the result of its own call.
+        self.stabiliser_group_cells = None
 
     def fix_projection_matrices_(self):
         self.feature_redraw_interval = None

@@ -33,28 +33,30 @@ def data_mask_device(data: torch.Tensor, mask_prob: float, replace_prob: float, 
 
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, ignore_index):
+    def forward(ctx, logits, labels, ignore_index, group_tokens):
         from . import ops
         lg = logits.contiguous()
         lb = labels.contiguous()
-        out = ops.ce_fwd(lg, lb, ignore_index)
+        out = ops.ce_fwd(lg, lb, ignore_index, group_tokens)
         ctx.save_for_backward(lg, lb, out)
-        ctx.ignore_index = ignore_index
-        return out[0]
+        ctx.ignore_index, ctx.group_tokens = ignore_index, group_tokens
+        return out[:, 0] if group_tokens else out[0, 0]
 
     @staticmethod
     def backward(ctx, dloss):
         from . import ops
         lg, lb, out = ctx.saved_tensors
-        d = ops.ce_bwd(lg, lb, ctx.ignore_index, dloss.to(torch.float32).contiguous(), out)
-        return d, None, None
+        d = ops.ce_bwd(lg, lb, ctx.ignore_index, dloss.to(torch.float32).reshape(-1).contiguous(), out, ctx.group_tokens)
+        return d, None, None, None
 
 
-def masked_cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int) -> torch.Tensor:
+def masked_cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int,
+                         group_cells: int = 0) -> torch.Tensor:
     """CrossEntropyLoss(ignore_index=..., reduction='mean')(logits.transpose(1, 2), labels) of the S1 loop
     (s1_pretrain_rna.py:268,297) on the un-transposed f32 logits [B, N, C<=8]: two small kernels forward, one
-    backward."""
-    return _MaskedCE.apply(logits, labels, ignore_index)
+    backward.  group_cells > 0: the batch holds several micro-batches of group_cells cells each (one accumulation
+    window run as one launch chain); the result is the vector of their losses, one mean per micro-batch."""
+    return _MaskedCE.apply(logits, labels, ignore_index, group_cells * logits.shape[-2] if group_cells else 0)
 
 
 def synthetic_tokens(seed: int, batch: int, n: int, device=None) -> torch.Tensor:

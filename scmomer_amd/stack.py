@@ -223,10 +223,11 @@ def _out_product(a: torch.Tensor, w: torch.Tensor, bias, resid, next_ln: Optiona
 
 
 def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[torch.Tensor], save: bool,
-             pre_ln: Optional[tuple] = None, next_ln: Optional[tuple] = None):
+             pre_ln: Optional[tuple] = None, next_ln: Optional[tuple] = None, group_cells: Optional[int] = None):
     """x: f32 [B,N,D].  Returns (y f32 [B,N,D] = resid + to_out(attn(LN(x))) + bias, tape, ln_y).
     pre_ln: (h, mean, rstd) when the producer of x already applied this sublayer's LayerNorm.
-    next_ln: (gamma, beta) of the sublayer that reads y: ln_y = its (h, mean, rstd), else None."""
+    next_ln: (gamma, beta) of the sublayer that reads y: ln_y = its (h, mean, rstd), else None.
+    group_cells: cells per key-stabiliser group (None: one stabiliser over the batch, performer_pytorch.py:90)."""
     b, n, d = x.shape
     t = b * n
     heads = p["heads"]
@@ -247,7 +248,8 @@ def attn_fwd(x: torch.Tensor, p: dict, w: dict, *, ln: bool, resid: Optional[tor
     q, k, v = _qkv_views(qkv5)
     o = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device)
     oc = torch.empty((b, n, heads, ops.DIM_HEAD), dtype=BF16, device=x.device) if save else None
-    saved = ops.favor_fwd(q, k, v, w["omega_b"], o.permute(0, 2, 1, 3), oc.permute(0, 2, 1, 3) if save else None)
+    saved = ops.favor_fwd(q, k, v, w["omega_b"], o.permute(0, 2, 1, 3), oc.permute(0, 2, 1, 3) if save else None,
+                          group_cells)
     y, ln_y = _out_product(o.view(t, inner), w["wo"], p["bo"], resid.reshape(t, d) if resid is not None else None, next_ln)
     tape = AttnTape(x2 if ln else None, h, mean, rstd, qkv5, o, oc, saved, (b, n, d)) if save else None
     return y.view(b, n, d), tape, ln_y
@@ -407,6 +409,7 @@ class StackSpec:
     head_out_shape: Optional[str] = None     # 'linear' | 'conv' | None (encodings only)
     token_err: Optional[torch.Tensor] = None  # device int32 [1]: set by the embedding kernel on a bad token id
     save: bool = True
+    group_cells: Optional[int] = None        # cells per key-stabiliser group (None: the whole batch)
 
 
 def _flat_params(spec: StackSpec) -> List[torch.Tensor]:
@@ -513,7 +516,7 @@ class _StackFn(torch.autograd.Function):
             chain = not spec.save and fp["c1"] is not None and ops.ffn_chain_supported(b_ * n_, d_, fp["w1"].shape[0])
             # the output product of a sublayer also applies the LayerNorm of the sublayer that follows it
             x1, at, ln2 = attn_fwd(x, ap, aw, ln=True, resid=x, save=spec.save, pre_ln=pre_ln,
-                                   next_ln=None if chain else (fp["g2"], fp["b2"]))
+                                   next_ln=None if chain else (fp["g2"], fp["b2"]), group_cells=spec.group_cells)
             pre_ln = None
             if chain:
                 # no tape: the whole FeedForward sublayer in one launch, which also applies the next layer's LayerNorm
@@ -636,7 +639,9 @@ def _build_spec(owner, layer_list, *, save: bool) -> StackSpec:
                 names.append((li, k))
         for k in FFN_KEYS:
             names.append((li, k))
-    return StackSpec(layers=layers, cache=_cache_of(owner), names=names, save=save)
+    performer = getattr(owner, "performer", owner)
+    return StackSpec(layers=layers, cache=_cache_of(owner), names=names, save=save,
+                     group_cells=getattr(performer, "stabiliser_group_cells", None))
 
 
 def _head_kind(to_out, dim: int):

@@ -119,6 +119,16 @@ def s1_batch_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int) -
     return torch.true_divide(correct_num, pred_num).mean()
 
 
+def s1_cell_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int) -> torch.Tensor:
+    """correct / predicted over the masked positions of every cell, f32 [B] (nan for a cell without masked
+    positions); s1_batch_accuracy is its mean."""
+    if logits.is_cuda and logits.dim() == 3 and logits.dtype == torch.float32:
+        from . import ops
+        return ops.s1_accuracy(logits.contiguous(), labels.contiguous(), pad_id)[0]
+    correct_num, pred_num = _cell_counts(logits, labels, pad_id)
+    return torch.true_divide(correct_num, pred_num).to(torch.float32)
+
+
 def _cell_counts(logits: torch.Tensor, labels: torch.Tensor, pad_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """(correct, counted) per cell, int64 [B] each."""
     if logits.is_cuda and logits.dim() == 3 and logits.dtype == torch.float32:
@@ -189,19 +199,38 @@ def _device_loss(logits, labels, pad_id):
 # ------------------------------------------------------------------------------------------------
 # the driver
 # ------------------------------------------------------------------------------------------------
+class _Recorded:
+    """One recorded launch chain: the HIP graph of a micro-step (or of a window of micro-steps) for one batch shape,
+    with its static input and output buffers."""
+    __slots__ = ("graph", "static_in", "static_out")
+
+    def __init__(self, graph, static_in, static_out):
+        self.graph, self.static_in, self.static_out = graph, static_in, static_out
+
+
 class S1Trainer:
     """Owns optimizer, schedule, gradient accumulators and the data-parallel exchange for one model replica.
 
     ``mask_fn(data, mask_prob, replace_prob, pad_id, mask_id) -> (masked_input, labels)`` and
     ``loss_fn(logits, labels, pad_id) -> scalar`` default to the device kernels (there is no CPU path behind
-    them); host tests inject torch formulations to drive the bookkeeping without a GPU."""
+    them); host tests inject torch formulations to drive the bookkeeping without a GPU.
+
+    ``window``: how many consecutive micro-steps ``window_step`` (and ``train_epoch``) run as ONE launch chain.  The
+    micro-steps of an accumulation window share one set of weights (s1_pretrain_rna.py:294-305: no optimizer step
+    in between), so ``window`` micro-batches stacked along dim 0 go through the encoder in one forward and one
+    backward pass; what the reference computes per micro-batch stays per micro-batch: the key stabiliser of the
+    attention (one max per forward call, performer_pytorch.py:89-90), the mean of the loss and the random draws of
+    the masking.  ``grad_acc`` must be a multiple of ``window``."""
 
     def __init__(self, model, *, learning_rate: float = 1e-4, grad_acc: int = 20, mask_prob: float = 0.15,
                  replace_prob: float = 0.9, bin_num: int = 5, max_grad_norm: float = int(1e2),
                  group: Optional[dist.ProcessGroup] = None, use_graph: bool = False,
-                 mask_fn: Optional[Callable] = None, loss_fn: Optional[Callable] = None):
+                 mask_fn: Optional[Callable] = None, loss_fn: Optional[Callable] = None, window: int = 1):
         self.model = model
         self.grad_acc = int(grad_acc)
+        self.window = int(window)
+        if self.window < 1 or self.grad_acc % self.window != 0:
+            raise ValueError(f"grad_acc ({grad_acc}) must be a multiple of window ({window})")
         self.mask_prob, self.replace_prob = mask_prob, replace_prob
         self.num_classes = bin_num + 2                       # s1_pretrain_rna.py:154-156
         self.pad_id = self.mask_id = self.num_classes - 1
@@ -227,33 +256,74 @@ class S1Trainer:
         if performer is not None and self.world > 1:
             performer.redraw_sync = lambda perf: sdist.broadcast_projections(perf, src=0, group=group)
         self.index = 0                                       # micro-steps since the start of the epoch
-        self._seed = None                                    # 1/grad_acc on the device: the backward's seed
+        self._seeds: Dict[Tuple[torch.device, int], torch.Tensor] = {}   # 1/grad_acc per loss: the backward's seed
         self.use_graph = use_graph
-        self._graph = None
-        self._graph_shape = None
+        self._recorded: Dict[Tuple[tuple, int], _Recorded] = {}
+        self._graph_auto = None                              # the model's own redraw switch while graphs exist
 
-    # ---- one micro-step ---------------------------------------------------------------------
-    def _forward_backward(self, data: torch.Tensor):
-        masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
-        logits = self.model(masked)
-        raw = self.loss_fn(logits, labels, self.pad_id)
+    # ---- one micro-step, or a window of them -------------------------------------------------
+    def _mask_window(self, data: torch.Tensor, groups: int):
+        """The masking of `groups` stacked micro-batches, with the random draws made micro-batch by micro-batch in
+        the order the reference makes them (pick draws, then replace draws: s1_pretrain_rna.py:114-119), so that a
+        window consumes the generator exactly as the same micro-steps run one by one."""
+        b = data.shape[0] // groups
+        if self.mask_fn is not _device_mask:
+            parts = [self.mask_fn(data[g * b:(g + 1) * b], self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
+                     for g in range(groups)]
+            return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+        pick = torch.empty(data.shape, dtype=torch.float32, device=data.device)
+        repl = torch.empty(data.shape, dtype=torch.float32, device=data.device)
+        for g in range(groups):
+            torch.rand((b,) + tuple(data.shape[1:]), out=pick[g * b:(g + 1) * b])
+            repl[g * b:(g + 1) * b].uniform_(0, 1)
+        return s1.data_mask_device(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id, pick, repl)
+
+    def _forward_backward(self, data: torch.Tensor, groups: int = 1):
+        """groups == 1: one micro-step -> (loss / grad_acc, accuracy) as device scalars.  groups > 1: data holds that
+        many micro-batches stacked along dim 0 -> the same two values per micro-batch, as vectors [groups]."""
+        if groups > 1 and data.shape[0] % groups != 0:
+            raise ValueError(f"a window of {groups} micro-batches needs a multiple of {groups} cells, got {data.shape[0]}")
+        b = data.shape[0] // groups
+        performer = getattr(self.model, "performer", None)
+        if groups == 1:
+            masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
+            logits = self.model(masked)
+            raw = self.loss_fn(logits, labels, self.pad_id)
+        else:
+            masked, labels = self._mask_window(data, groups)
+            if performer is not None:
+                before = performer.stabiliser_group_cells
+                performer.stabiliser_group_cells = b        # one key stabiliser per micro-batch
+            try:
+                logits = self.model(masked)
+            finally:
+                if performer is not None:
+                    performer.stabiliser_group_cells = before
+            if self.loss_fn is _device_loss:
+                raw = s1.masked_cross_entropy(logits, labels, self.pad_id, group_cells=b)
+            else:
+                raw = torch.stack([self.loss_fn(logits[g * b:(g + 1) * b], labels[g * b:(g + 1) * b], self.pad_id)
+                                   for g in range(groups)])
         loss = raw / self.grad_acc
         if self.params:
             # autograd.grad hands the gradients back without going through the parameters' AccumulateGrad nodes (which
             # are tied to the stream they were created on: recording this step on a side stream would mix streams).
-            # The backward starts from the unscaled loss with 1/grad_acc as its seed: the value the division's own
-            # backward would pass on (1.0 * 1/grad_acc), without its two small kernels.
-            if self._seed is None or self._seed.device != raw.device:
-                self._seed = torch.full((), 1.0, dtype=raw.dtype, device=raw.device) / self.grad_acc
+            # The backward starts from the unscaled losses with 1/grad_acc as the seed of each: the value the
+            # division's own backward would pass on (1.0 * 1/grad_acc), without its two small kernels.
+            key = (raw.device, groups)
+            if key not in self._seeds:
+                self._seeds[key] = torch.full(raw.shape, 1.0, dtype=raw.dtype, device=raw.device) / self.grad_acc
             # the encoder's backward adds its gradients into the accumulators itself (its last launch, the batched
             # reductions, does the add); what it hands back are the gradients of anything outside the fused stack
             from . import stack
             with stack.grad_sink(self.params, self.accs):
-                grads = torch.autograd.grad(raw, self.params, grad_outputs=self._seed, allow_unused=True)
+                grads = torch.autograd.grad(raw, self.params, grad_outputs=self._seeds[key], allow_unused=True)
             left = [(a, g) for a, g in zip(self.accs, grads) if g is not None]
             if left:
                 torch._foreach_add_([a for a, _ in left], [g for _, g in left])
-        return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
+        if groups == 1:
+            return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
+        return loss.detach(), s1_cell_accuracy(logits.detach(), labels, self.pad_id).view(groups, b).mean(dim=1)
 
     def _optimizer_step(self):
         """The sync micro-step's tail (s1_pretrain_rna.py:299-305): average over ranks, clip, Adam, zero."""
@@ -267,24 +337,26 @@ class S1Trainer:
             torch._foreach_zero_(self.accs)
         for p in self.params:
             p.grad = None
-        if self._graph is not None:
+        if self._recorded:
             from . import stack
-            stack.refresh_weights(self.model)                # the graph reads the bf16 copies in place
+            stack.refresh_weights(self.model)                # the graphs read the bf16 copies in place
 
-    def _capture(self, data: torch.Tensor):
-        """Record the micro-step for this batch shape once; the redraw check stays outside the recording."""
-        self._static_in = data.clone()
-        self._static_out = [torch.zeros((), device=data.device), torch.zeros((), device=data.device)]
+    def _capture(self, data: torch.Tensor, groups: int = 1) -> _Recorded:
+        """Record the launch chain for this batch shape once; the redraw check stays outside the recording."""
+        static_in = data.clone()
+        shape = () if groups == 1 else (groups,)
+        static_out = [torch.zeros(shape, device=data.device), torch.zeros(shape, device=data.device)]
         saved = [a.clone() for a in self.accs]
         performer = getattr(self.model, "performer", None)
-        auto = performer.auto_check_redraw if performer is not None else None
+        if performer is not None and not self._recorded:
+            self._graph_auto = performer.auto_check_redraw
         if performer is not None:
             performer.auto_check_redraw = False
 
         def body():
-            loss, acc = self._forward_backward(self._static_in)
-            self._static_out[0].copy_(loss)
-            self._static_out[1].copy_(acc)
+            loss, acc = self._forward_backward(static_in, groups)
+            static_out[0].copy_(loss)
+            static_out[1].copy_(acc)
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -300,55 +372,71 @@ class S1Trainer:
             body()
         for a, s_ in zip(self.accs, saved):                  # warm-up and recording passes do not count
             a.copy_(s_)
-        self._graph, self._graph_shape, self._graph_auto = graph, tuple(data.shape), auto
+        rec = _Recorded(graph, static_in, static_out)
+        self._recorded[(tuple(data.shape), groups)] = rec
+        return rec
 
     def release_graph(self) -> None:
-        """Drop the recorded micro-step (the next micro_step records again) and hand the redraw check back to the
+        """Drop the recorded launch chains (the next step records again) and hand the redraw check back to the
         model's own forward, e.g. before the model is used outside this driver."""
         performer = getattr(self.model, "performer", None)
-        if self._graph is not None and performer is not None:
+        if self._recorded and performer is not None:
             performer.auto_check_redraw = self._graph_auto
-        self._graph = self._graph_shape = None
+        self._recorded = {}
 
-    def prepare(self, example: torch.Tensor) -> None:
-        """Record the micro-step graph for batches shaped like ``example`` now (otherwise the first micro_step
-        does it).  The warm-up passes of the recording leave weights and accumulators untouched."""
-        if self.use_graph and example.is_cuda and self._graph is None:
-            self._capture(example)
+    def prepare(self, example: torch.Tensor, groups: int = 1) -> None:
+        """Record the graph for batches shaped like ``example`` now (otherwise the first step of that shape does it);
+        groups > 1: ``example`` is a window of that many stacked micro-batches.  The warm-up passes of the recording
+        leave weights and accumulators untouched."""
+        if self.use_graph and example.is_cuda and (tuple(example.shape), groups) not in self._recorded:
+            self._capture(example, groups)
+
+    def _run(self, data: torch.Tensor, groups: int):
+        """`groups` micro-steps over `data` as one launch chain: replayed from its graph when graphs are in use."""
+        performer = getattr(self.model, "performer", None)
+        if self.use_graph and data.is_cuda:
+            rec = self._recorded.get((tuple(data.shape), groups)) or self._capture(data, groups)
+            if performer is not None and self._graph_auto:
+                for _ in range(groups):                      # one tick of the redraw counter per micro-step
+                    performer.check_redraw_projections()     # host-side bookkeeping; a redraw needs fresh copies
+                from . import stack
+                stack.refresh_weights(self.model)
+            rec.static_in.copy_(data)
+            rec.graph.replay()
+            return rec.static_out[0].clone(), rec.static_out[1].clone()
+        if performer is not None and groups > 1 and performer.auto_check_redraw:
+            for _ in range(groups - 1):                      # the model's forward ticks once itself
+                performer.check_redraw_projections()
+        return self._forward_backward(data, groups)
 
     def micro_step(self, data: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """One pass of s1_pretrain_rna.py:287-305 over a batch of tokens int64 [B, N].  -> (loss / grad_acc,
         batch accuracy) as device scalars; nothing waits for the device."""
         self.index += 1
-        if self.use_graph and data.is_cuda:
-            if self._graph is None:
-                self._capture(data)
-            if tuple(data.shape) == self._graph_shape:
-                performer = getattr(self.model, "performer", None)
-                if performer is not None and self._graph_auto:
-                    performer.check_redraw_projections()     # host-side bookkeeping; a redraw needs fresh copies
-                    from . import stack
-                    stack.refresh_weights(self.model)
-                self._static_in.copy_(data)
-                self._graph.replay()
-                loss, acc = self._static_out[0].clone(), self._static_out[1].clone()
-            else:
-                loss, acc = self._eager(data)
-        else:
-            loss, acc = self._eager(data)
+        loss, acc = self._run(data, 1)
         if self.index % self.grad_acc == 0:
             self._optimizer_step()
         return loss, acc
 
-    def _eager(self, data):
-        performer = getattr(self.model, "performer", None)
-        if self._graph is not None and performer is not None:
-            performer.auto_check_redraw = self._graph_auto
-            try:
-                return self._forward_backward(data)
-            finally:
-                performer.auto_check_redraw = False
-        return self._forward_backward(data)
+    def window_step(self, data: torch.Tensor, groups: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``groups`` (default: ``window``) consecutive micro-steps of s1_pretrain_rna.py:287-305 as one launch chain.
+        data: int64 [groups * B, N], the micro-batches stacked in the order the loop would have met them.
+        -> (loss / grad_acc, batch accuracy) per micro-batch, device vectors [groups].  Every micro-batch gets what
+        its own micro-step would have given it (own key stabiliser, own loss mean, own mask draws); the gradients
+        add up in the accumulators in a different order (rounding differences only).  The window must not straddle
+        an optimizer step; a projection redraw that falls due inside a window happens before the whole window."""
+        groups = self.window if groups is None else int(groups)
+        if groups == 1:
+            loss, acc = self.micro_step(data)
+            return loss.reshape(1), acc.reshape(1)
+        if self.index % self.grad_acc + groups > self.grad_acc:
+            raise ValueError(f"a window of {groups} micro-steps starting at micro-step {self.index} would straddle the "
+                             f"optimizer step (grad_acc {self.grad_acc})")
+        self.index += groups
+        loss, acc = self._run(data, groups)
+        if self.index % self.grad_acc == 0:
+            self._optimizer_step()
+        return loss, acc
 
     # ---- epochs -----------------------------------------------------------------------------
     def _mean_over_ranks(self, value: torch.Tensor) -> float:
@@ -375,11 +463,34 @@ class S1Trainer:
         self.index = 0
         running_loss = running_acc = None
         n = 0
+
+        def account(loss, acc, count):
+            nonlocal running_loss, running_acc, n
+            running_loss = loss.sum() if running_loss is None else running_loss + loss.sum()
+            running_acc = acc.sum() if running_acc is None else running_acc + acc.sum()
+            n += count
+
+        held: List[torch.Tensor] = []                       # micro-batches waiting for their window to fill up
+
+        def flush(as_window: bool):
+            if as_window and self.index % self.grad_acc + len(held) <= self.grad_acc:
+                account(*self.window_step(torch.cat(held, dim=0), len(held)), len(held))
+            else:
+                for h_ in held:
+                    account(*self.micro_step(h_), 1)
+            held.clear()
+
         for data in batches:
-            loss, acc = self.micro_step(data)
-            running_loss = loss if running_loss is None else running_loss + loss
-            running_acc = acc if running_acc is None else running_acc + acc
-            n += 1
+            if self.window == 1:
+                account(*self.micro_step(data), 1)
+                continue
+            if held and tuple(data.shape) != tuple(held[0].shape):
+                flush(False)                                 # a ragged batch (the epoch's last): one by one
+            held.append(data)
+            if len(held) == self.window:
+                flush(True)
+        if held:
+            flush(False)
         if n == 0:
             raise ValueError("empty epoch")
         epoch_loss = self._mean_over_ranks(running_loss / n)
