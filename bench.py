@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grad-acc", type=int, default=5, help="micro-steps per optimizer step (README uses 5)")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--window", type=int, default=5,
+                    help="micro-steps run as one launch chain (they share the weights of their accumulation window; "
+                         "key stabiliser, loss mean and mask draws stay per 3-cell micro-batch); must divide "
+                         "--grad-acc; 1 = one launch chain per micro-step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-all", action="store_true", help="time every kernel (per-kernel table to stderr)")
     ap.add_argument("--eager", action="store_true", help="drive every launch from Python instead of a HIP graph")
@@ -464,18 +468,28 @@ def main():
     # the gradients over the ranks (one flat all-reduce), clips, applies Adam and refreshes the bf16 weight copies
     # (s1_pretrain_rna.py:287-312).  The micro-step is launch-bound when driven from Python (about 250 kernel
     # launches), so the driver records it once into a HIP graph and replays it.
+    if args.grad_acc % args.window != 0:
+        raise SystemExit(f"bench.py: --window {args.window} must divide --grad-acc {args.grad_acc}")
+    G = args.window
     trainer = train.S1Trainer(model, learning_rate=1e-4, grad_acc=args.grad_acc, mask_prob=0.15, replace_prob=0.9,
-                              use_graph=not args.eager)
+                              use_graph=not args.eager, window=G)
 
     # each rank owns its own shard of synthetic cells (resident in HBM before timing starts)
     n_batches = 4
-    data = [s1.synthetic_tokens(1000 * rank + i, args.batch, N_GENES, device) for i in range(n_batches)]
+    # one step = one launch chain = G micro-batches of --batch cells stacked along dim 0
+    data = [s1.synthetic_tokens(1000 * rank + i, G * args.batch, N_GENES, device) for i in range(n_batches)]
     last = {}
 
     def step(i):
-        last["loss"], last["acc"] = trainer.micro_step(data[i % n_batches])
+        loss, acc = trainer.window_step(data[i % n_batches], G)
+        last["loss"], last["acc"] = loss[-1], acc[-1]
 
-    trainer.prepare(data[0])
+    trainer.prepare(data[0], G)
+    # set-up, like the graph recording above: one full accumulation window, so that the first optimizer step (which
+    # allocates Adam's moments and loads its kernels: tens of milliseconds, once) is not part of the measurement
+    # whatever --warmup is
+    for i in range(args.grad_acc // G):
+        step(i)
     graph = None if args.eager else True
     _say("graph captured" if graph is not None else "eager mode")
     for i in range(args.warmup):
@@ -505,13 +519,13 @@ def main():
     ops.trace_enable("all")
     traced_steps = 3
     for i in range(traced_steps):
-        trainer._forward_backward(data[i % n_batches])
+        trainer._forward_backward(data[i % n_batches], G)
     torch.cuda.synchronize()
     ops.trace_enable(None)
     trace = ops.trace_collect()
 
     if rank == 0:
-        cells = world * args.batch * args.steps
+        cells = world * G * args.batch * args.steps
         value = cells / dt
         # the dominant kernel = the traced kernel with the largest share of the step
         dominant = os.environ.get("SCM_BENCH_TRACE_KERNEL") or max(trace, key=lambda k: trace[k][0])
@@ -538,7 +552,7 @@ def main():
                 "hbm_achievable_gbs": HBM_ACHIEVABLE_GBS, "frac_of_achievable_hbm": gbs / HBM_ACHIEVABLE_GBS,
                 "mfma_util": mfma_util, "valu_busy": valu_busy, "utilisation_source": util_src,
                 "algorithmic_bytes_per_step_all_kernels": step_bytes,
-                "algorithmic_bytes_per_step_lower_bound": 365e6 * args.batch,
+                "algorithmic_bytes_per_step_lower_bound": 365e6 * args.batch * G,
                 "avg_launch_ms": ms / cnt, "launches_per_step": cnt / traced_steps,
                 "algorithmic_bytes_per_launch": by / cnt, "algorithmic_flops_per_launch": fl / cnt,
                 "tflops": tflops, "gbs": gbs, "share_of_kernel_time": ms / sum(v[0] for v in trace.values()),
@@ -559,13 +573,16 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic",
-               "config": {"workload": "S1 RNA masked-autoencoding pretrain micro-step (mask_prob 0.15): mask + "
-                                      "Performer encoder fwd + CE + bwd + accuracy; gradient average, clip + Adam "
-                                      "every grad_acc steps (scmomer_amd.train.S1Trainer)",
-                          "cells_per_gpu_per_step": args.batch, "gene_tokens": N_GENES, "depth": 6, "dim": 200,
+               "config": {"workload": "S1 RNA masked-autoencoding pretrain (mask_prob 0.15, batch 3): mask + Performer "
+                                      "encoder fwd + CE + bwd + accuracy per micro-step; gradient average, clip + Adam "
+                                      f"every grad_acc micro-steps (scmomer_amd.train.S1Trainer); {G} micro-step(s) of "
+                                      f"{args.batch} cells per launch chain (one step), key stabiliser, loss mean and "
+                                      f"mask draws per {args.batch}-cell micro-batch as in the reference's loop",
+                          "cells_per_gpu_per_step": G * args.batch, "micro_batch_cells": args.batch,
+                          "micro_steps_per_launch_chain": G, "gene_tokens": N_GENES, "depth": 6, "dim": 200,
                           "heads": 10, "nb_features": 266, "grad_acc": args.grad_acc,
                           "parallelism": f"dp{world}", "feature_redraw": "disabled",
-                          "launch": "eager" if args.eager else "hip-graph replay of the micro-step"},
+                          "launch": "eager" if args.eager else "hip-graph replay of the launch chain"},
                "final_loss": final_loss, "final_batch_accuracy": final_acc, "roofline": roof, "cpu_baseline": base, "kernels": kernels}
         print(json.dumps(out))
     if world > 1:

@@ -12,8 +12,11 @@
  *     statistics, gradients of parameters and all accumulations are f32;
  *   - every function returns 0 on success, a negative SCM_E* code on a rejected argument, or a
  *     positive hipError_t from the launch; scm_last_error() gives the text (host, thread-local);
- *   - T = B*N tokens, D = model dim (<= 256, multiple of 8), head dim is 64 and the number of
- *     random features is 266 (compile-time constants of the path).
+ *   - T = B*N tokens, D = model dim (multiple of 8; <= 256 for the row-wise kernels, <= 224 / 220 for the products
+ *     with LayerNorm epilogues, 200 for the chained FeedForward; the module API accepts dim <= 200), head dim is 64
+ *     and the number of random features is 266 (compile-time constants of the path);
+ *   - no tensor size limit other than T < 2^31: the kernels address with 32-bit offsets inside 2 GiB windows, and
+ *     the entry points walk tall inputs in row slabs (products) or re-base per token slice / per (cell, head).
  */
 #ifndef SCMOMER_HIP_H
 #define SCMOMER_HIP_H
@@ -35,6 +38,9 @@ typedef struct { void* p; int64_t sb, sh, sn; } scm_view4;
 
 int scm_version(void);
 const char* scm_last_error(void); /* host */
+/* Diagnostic: how many products have run on the general register-staged kernel since the library was loaded (shapes
+ * that none of the asynchronous-copy kernels takes; the encoder's own shapes never do, at any batch size). */
+int64_t scm_gemm_general_launches(void);
 
 /* ---- parameter preparation ------------------------------------------------------------- */
 /* f32 weight [rows,cols] -> bf16 copy and/or bf16 transposed copy [cols,rows] (either may be NULL). */
@@ -111,8 +117,9 @@ int scm_gemm_nt(int epi, int a_f32, const void* A, int64_t lda, const void* W_bf
  *      f32 product rows stay on the chip.  A [M,K] bf16, W [D,K] bf16; x, dres, dx: [M,D] f32, contiguous rows;
  *      other arguments as scm_ln_bwd (dgamma, dbeta, dres_colsum may all be NULL: then the column partials are left
  *      in ws, [scm_gemm_ln_bwd_ws_floats(M,D) / (3 D)][3 D], for a later scm_reduce_batch).
- *      Sizes: scm_gemm_ln_bwd_supported (D <= 224, D % 4 == 0, K >= 128, K % 8 == 0, M D < 2^28); other sizes are
- *      rejected with SCM_EINVAL and take the two separate calls. */
+ *      Sizes: scm_gemm_ln_bwd_supported (D <= 224, D % 4 == 0, K >= 128, K % 8 == 0, lda <= 2340, any M: inputs taller
+ *      than 458,752 rows run as row slabs of that height); other sizes are rejected with SCM_EINVAL and take the
+ *      two separate calls. */
 int scm_gemm_ln_bwd_supported(int64_t M, int D, int K, int64_t lda, int64_t ldw);
 int64_t scm_gemm_ln_bwd_ws_floats(int64_t M, int D);
 int scm_gemm_ln_bwd(const void* A_bf16, int64_t lda, const void* W_bf16, int64_t ldw, int64_t M, int D, int K,
@@ -125,7 +132,7 @@ int scm_gemm_ln_bwd(const void* A_bf16, int64_t lda, const void* W_bf16, int64_t
  *      residual add of reversible.py:144-145), then h = LN(y) for the PreLayerNorm (:289-295) that reads y next.
  *      It replaces scm_gemm_nt(SCM_EPI_F32_BIAS_RES) followed by scm_ln_fwd: y is not read back.
  *      A [M,K] bf16, W [D,K] bf16; resid (may be NULL), y: [M,D] f32, contiguous rows; h [M,D] bf16; mean, rstd [M].
- *      Sizes: scm_gemm_res_ln_supported (D <= 220, D % 4 == 0, K >= 128, K % 8 == 0, M D < 2^28). */
+ *      Sizes: scm_gemm_res_ln_supported (D <= 220, D % 4 == 0, K >= 128, K % 8 == 0, lda <= 2340, any M). */
 int scm_gemm_res_ln_supported(int64_t M, int D, int K, int64_t lda, int64_t ldw);
 int scm_gemm_res_ln(const void* A_bf16, int64_t lda, const void* W_bf16, int64_t ldw, int64_t M, int D, int K,
                     const float* bias, const float* resid, float* y, const float* gamma, const float* beta,

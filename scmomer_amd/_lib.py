@@ -51,6 +51,7 @@ class FfnFwdArgs(C.Structure):
 SIGNATURES = {
     "scm_version": (i32, []),
     "scm_last_error": (C.c_char_p, []),
+    "scm_gemm_general_launches": (i64, []),
     "scm_cast_weight": (i32, [vp, i32, i32, vp, vp, vp]),
     "scm_cast_weights_batch": (i32, [vp, i32, vp]),
     "scm_prep_omega": (i32, [vp, vp, vp]),

@@ -93,6 +93,7 @@ int scm_trace_collect(double* ms, double* flops, double* bytes, int64_t* launche
   return 0;
 }
 const char* scm_last_error(void) { return g_err; }
+int64_t scm_gemm_general_launches(void) { return (int64_t)gemm_general_launches(); }
 
 int scm_cast_weights_batch(const scm_cast_item* items, int n, void* stream) {
   SCM_REQ(items && n > 0 && n <= 65535, "scm_cast_weights_batch: bad arguments");
@@ -291,8 +292,11 @@ int scm_wgrad_multi(const scm_wgrad_item* items, int n, int64_t T, int slices, v
     SCM_REQ(it->ldp >= it->P && it->ldq >= it->Q && it->ldp % 8 == 0 && it->ldq % 8 == 0 && aligned16(it->Pm) &&
                 aligned16(it->Qm),
             "scm_wgrad_multi: bad leading dimension or alignment");
-    SCM_REQ(T * it->ldp * 2 < (1ll << 31) && T * it->ldq * 2 < (1ll << 31),
-            "scm_wgrad_multi: operands of 2 GiB or more: use scm_wgrad");
+    {
+      const int64_t slice_tokens = (((T + 63) / 64 + slices - 1) / slices) * 64;
+      SCM_REQ(slice_tokens * it->ldp * 2 < 0x7FFFF000ll && slice_tokens * it->ldq * 2 < 0x7FFFF000ll,
+              "scm_wgrad_multi: a token slice of 2 GiB or more: use more slices");
+    }
     d[i] = WgradDesc{it->Pm, (long)it->ldp, it->Qm, (long)it->ldq, it->ws, it->P, it->Q, it->with_bias ? 1 : 0};
   }
   SCM_HIP(wgrad_multi(d, n, (int)T, slices, (hipStream_t)stream), "scm_wgrad_multi");

@@ -290,22 +290,48 @@ int ffn_chain_grid(long M) {
 }
 
 bool ffn_chain_supported(long M, int D, int F) {
-  return D == 200 && F >= 8 && F % 8 == 0 && F <= FC_MAXF && M > 0 && M * (long)F * 2 < (1l << 31) &&
-         M * (long)D * 4 < (1l << 31);
+  return D == 200 && F >= 8 && F % 8 == 0 && F <= FC_MAXF && M > 0;
 }
 
+// The kernel forms 32-bit byte offsets from row numbers and leading dimensions: a tall input runs as several launches
+// over row slabs (rows are independent), each slab with every operand below 2 GiB.
 hipError_t ffn_chain(FfnChainArgs a, hipStream_t s) {
   const size_t lds = 2 * FC_STAGE + (FC_MAXF + 5 * FC_VEC) * sizeof(float);
   static std::atomic<unsigned long long> ready;
   if (hipError_t e = ensure_dynamic_lds((const void*)ffn_chain_kernel, lds, ready); e != hipSuccess) return e;
-  const int grid = ffn_chain_grid(a.M);
-  const double M = (double)a.M, D = 200.0, F = (double)a.F;
-  // algorithmic bytes: x in, y out (+ pre, act, h when saved, + h_next); weights once
-  const double bytes = 2.0 * 2 * D * F +
-                       M * (D * 8 + (a.pre ? F * 2 : 0) + (a.act ? F * 2 : 0) + (a.h ? D * 2 : 0) + (a.h_n ? D * 2 : 0));
-  Traced tr(K_FFN_CHAIN_FWD, 4.0 * M * D * F, s, bytes);
-  hipLaunchKernelGGL(ffn_chain_kernel, dim3(grid), dim3(512), lds, s, a);
-  return hipGetLastError();
+  long row_bytes = a.ldx * 4;
+  if (a.ldy * 4 > row_bytes) row_bytes = a.ldy * 4;
+  if (a.h && a.ldh * 2 > row_bytes) row_bytes = a.ldh * 2;
+  if (a.pre && a.ldo0 * 2 > row_bytes) row_bytes = a.ldo0 * 2;
+  if (a.act && a.ldo1 * 2 > row_bytes) row_bytes = a.ldo1 * 2;
+  if (a.h_n && a.ldhn * 2 > row_bytes) row_bytes = a.ldhn * 2;
+  const long lim = (1l << 31) - 4096;
+  long rows = a.M;
+  if (a.M * row_bytes > lim) {
+    rows = lim / row_bytes / (256 * 32) * (256 * 32);      // whole rounds of 256 workgroups x 32-row tiles
+    if (rows < 32) return hipErrorInvalidValue;             // a leading dimension beyond 64 MiB per row
+  }
+  const long Mtot = a.M;
+  for (long r0 = 0; r0 < Mtot; r0 += rows) {
+    FfnChainArgs b = a;
+    b.M = Mtot - r0 < rows ? Mtot - r0 : rows;
+    b.x = a.x + r0 * a.ldx; b.y = a.y + r0 * a.ldy;
+    if (a.mean) b.mean = a.mean + r0;
+    if (a.rstd) b.rstd = a.rstd + r0;
+    if (a.h) b.h = a.h + r0 * a.ldh;
+    if (a.pre) b.pre = a.pre + r0 * a.ldo0;
+    if (a.act) b.act = a.act + r0 * a.ldo1;
+    if (a.h_n) { b.h_n = a.h_n + r0 * a.ldhn; b.mean_n = a.mean_n + r0; b.rstd_n = a.rstd_n + r0; }
+    const int grid = ffn_chain_grid(b.M);
+    const double M = (double)b.M, D = 200.0, F = (double)a.F;
+    // algorithmic bytes: x in, y out (+ pre, act, h when saved, + h_next); weights once
+    const double bytes = 2.0 * 2 * D * F +
+                         M * (D * 8 + (a.pre ? F * 2 : 0) + (a.act ? F * 2 : 0) + (a.h ? D * 2 : 0) + (a.h_n ? D * 2 : 0));
+    Traced tr(K_FFN_CHAIN_FWD, 4.0 * M * D * F, s, bytes);
+    hipLaunchKernelGGL(ffn_chain_kernel, dim3(grid), dim3(512), lds, s, b);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace scm

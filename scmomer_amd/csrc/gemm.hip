@@ -1041,8 +1041,13 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradPair pr, int T, int
   const int tile_lo = slice * tiles_per_slice;
   const int tile_hi = min(ntiles, tile_lo + tiles_per_slice);
   const int qchunks = Q >> 3;
-  const u32x4 rP = dma_rsrc(Pm, (uint32_t)(((long)(T - 1) * ldp + P) * 2));
-  const u32x4 rQ = dma_rsrc(Qm, (uint32_t)(((long)(T - 1) * ldq + Q) * 2));
+  // The resources start at the slice's first token and end with the tensor, or just below 2 GiB, whichever comes
+  // first (a slice is shorter than that; BUF_OOB must stay out of range): offsets stay 32-bit however many tokens
+  // there are.
+  const long t_lo = (long)tile_lo * W_BT;
+  const long p_left = ((long)(T - 1) - t_lo) * ldp + P, q_left = ((long)(T - 1) - t_lo) * ldq + Q;
+  const u32x4 rP = dma_rsrc(Pm + t_lo * ldp, (uint32_t)(p_left <= 0 ? 0 : (p_left * 2 < 0x7FFFF000l ? p_left * 2 : 0x7FFFF000l)));
+  const u32x4 rQ = dma_rsrc(Qm + t_lo * ldq, (uint32_t)(q_left <= 0 ? 0 : (q_left * 2 < 0x7FFFF000l ? q_left * 2 : 0x7FFFF000l)));
   const int wu = __builtin_amdgcn_readfirstlane(w);   // wave index as a scalar (LDS copy bases live in M0)
   const uint32_t lds0 = lds_addr_of(smem);
 
@@ -1069,8 +1074,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradPair pr, int T, int
   auto issue_piece = [&](int tile, int buf, int i) {
     if (tile >= tile_hi) return;          // past the slice: nothing is copied (the stage is not read either)
     const uint32_t pb = lds0 + buf * WD_STAGE, qb = pb + WD_PBYTES;
-    if (i < 4) dma16_to_lds(rP, pb + 1024 * (4 * wu + i), pv[i], (uint32_t)((long)tile * W_BT * ldp * 2));
-    else if (!ONES || qmask[i - 4]) dma16_to_lds(rQ, qb + 1024 * (7 * wu + i - 4), qv[i - 4], (uint32_t)((long)tile * W_BT * ldq * 2));
+    if (i < 4) dma16_to_lds(rP, pb + 1024 * (4 * wu + i), pv[i], (uint32_t)((long)(tile - tile_lo) * W_BT * ldp * 2));
+    else if (!ONES || qmask[i - 4]) dma16_to_lds(rQ, qb + 1024 * (7 * wu + i - 4), qv[i - 4], (uint32_t)((long)(tile - tile_lo) * W_BT * ldq * 2));
   };
   auto issue = [&](int tile, int buf, int i0, int i1) {
 #pragma unroll
@@ -1283,10 +1288,15 @@ static double gemm_bytes(int M, int N, int K, const GemmEpi& e) {
   return b;
 }
 
+// products that ran on the general register-staged kernel (shapes none of the asynchronous-copy kernels takes)
+static std::atomic<long long> g_general_launches{0};
+long long gemm_general_launches() { return g_general_launches.load(std::memory_order_relaxed); }
+
 template <int NT, bool A_F32, int EPI>
 static hipError_t launch_gemm(const void* A, long lda, const bf16* W, long ldw, int M, int N, int K, GemmEpi e,
                               hipStream_t s) {
   constexpr int BN = NT * 32;
+  g_general_launches.fetch_add(1, std::memory_order_relaxed);
   dim3 grid((M + G_BM - 1) / G_BM, (N + BN - 1) / BN);
   size_t lds = (size_t)(G_BM + BN) * 128;
   if (lds < 4 * 32 * G_SP * sizeof(float)) lds = 4 * 32 * G_SP * sizeof(float);
@@ -1347,8 +1357,8 @@ static hipError_t dispatch_nt(const void* A, long lda, const bf16* W, long ldw, 
   return launch_gemm<4, A_F32, EPI>(A, lda, W, ldw, M, N, K, e, s);
 }
 
-hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
-                   GemmEpi e, hipStream_t s) {
+static hipError_t gemm_nt_one(int epi, int a_f32, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                              GemmEpi e, hipStream_t s) {
   const bf16* Wb = (const bf16*)W;
 #define SCM_CASE(E)                                                               \
   case E:                                                                         \
@@ -1366,12 +1376,52 @@ hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, l
   return hipErrorInvalidValue;
 }
 
+// The fast kernels address their operands with 32-bit byte offsets inside buffer resources, i.e. below 2 GiB.  Every
+// product here is independent row by row, so a taller problem runs as several launches over row slabs, each with
+// all of its operands below 2 GiB (thousands of row tiles per slab: the launches stay many rounds deep).
+static long slab_rows_for(long M, long row_bytes) {
+  const long lim = (1l << 31) - 4096;
+  if (M * row_bytes <= lim) return M;
+  const long n = (M * row_bytes + lim - 1) / lim;
+  long rows = ((M + n - 1) / n + 255) / 256 * 256;
+  while (rows * row_bytes > lim) rows -= 256;
+  return rows < 256 ? 256 : rows;
+}
+
+hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                   GemmEpi e, hipStream_t s) {
+  const long o0 = (epi == EPI_F32 || epi == EPI_F32_BIAS_RES) ? 4 : 2;   // bytes per element of out0
+  long row_bytes = lda * (a_f32 ? 4 : 2);
+  if (e.ldo0 * o0 > row_bytes) row_bytes = e.ldo0 * o0;
+  if (e.out1 && e.ldo1 * 2 > row_bytes) row_bytes = e.ldo1 * 2;
+  if (e.pre && e.ldp * 2 > row_bytes) row_bytes = e.ldp * 2;
+  if (e.resid && e.ldr * 4 > row_bytes) row_bytes = e.ldr * 4;
+  const long rows = slab_rows_for(M, row_bytes);
+  for (long r0 = 0; r0 < M; r0 += rows) {
+    const int m = (int)(M - r0 < rows ? M - r0 : rows);
+    GemmEpi g = e;
+    g.out0 = (char*)e.out0 + r0 * e.ldo0 * o0;
+    if (e.out1) g.out1 = (char*)e.out1 + r0 * e.ldo1 * 2;
+    if (e.resid) g.resid = e.resid + r0 * e.ldr;
+    if (e.pre) g.pre = e.pre + r0 * e.ldp;
+    const hipError_t err = gemm_nt_one(epi, a_f32, (const char*)A + r0 * lda * (a_f32 ? 4 : 2), lda, W, ldw, m, N, K, g, s);
+    if (err != hipSuccess) return err;
+  }
+  return hipSuccess;
+}
+
+// Row slabs of the two products with LayerNorm epilogues: a fixed slab height, so that the number of workgroups
+// (one column-partial record each) depends on M alone.
+constexpr long LN_SLAB_ROWS = 8l * 256 * GD_ROWS;   // 458,752 rows: 8 rounds of 256 workgroups
+constexpr long LN_SLAB_MAX_LD = ((1l << 31) - 4096) / (2 * LN_SLAB_ROWS);   // elements per A row that keep a slab below 2 GiB
+
 bool gemm_ln_bwd_supported(long M, int N, int K, long lda, long ldw) {
   const long lim = 1l << 31;
-  return N <= 224 && N % 4 == 0 && K >= 128 && K % 8 == 0 && M > 0 && M * lda * 2 < lim && (long)N * ldw * 2 < lim &&
-         M * N * 4 < (1l << 30);
+  return N <= 224 && N % 4 == 0 && K >= 128 && K % 8 == 0 && M > 0 && lda <= LN_SLAB_MAX_LD && (long)N * ldw * 2 < lim;
 }
-int gemm_ln_bwd_blocks(long M) { return (int)nt_dma_grid(M); }
+int gemm_ln_bwd_blocks(long M) {
+  return (int)((M / LN_SLAB_ROWS) * nt_dma_grid(LN_SLAB_ROWS) + (M % LN_SLAB_ROWS ? nt_dma_grid(M % LN_SLAB_ROWS) : 0));
+}
 
 hipError_t gemm_ln_bwd(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s) {
   if (!gemm_ln_bwd_supported(M, N, K, lda, ldw)) return hipErrorInvalidValue;
@@ -1379,11 +1429,21 @@ hipError_t gemm_ln_bwd(const void* A, long lda, const void* W, long ldw, int M, 
   static std::atomic<unsigned long long> ready;
   if (hipError_t err = ensure_dynamic_lds((const void*)gemm_nt_dma_kernel<EPI_LN_BWD>, (size_t)GD_LDS, ready); err != hipSuccess)
     return err;
-  const double bytes = (double)M * K * 2 + (double)N * K * 2 + (double)M * N * (4 + (e.resid ? 4 : 0) + 4 + (e.ln_dxb ? 2 : 0));
-  Traced tr(K_GEMM_LN_BWD, 2.0 * M * N * K, s, bytes);
-  hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LN_BWD>), dim3((unsigned)nt_dma_grid(M)), dim3(448), (size_t)GD_LDS, s,
-                     (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, e);
-  return hipGetLastError();
+  for (long r0 = 0; r0 < M; r0 += LN_SLAB_ROWS) {
+    const int m = (int)(M - r0 < LN_SLAB_ROWS ? M - r0 : LN_SLAB_ROWS);
+    GemmEpi g = e;
+    g.out0 = (float*)e.out0 + r0 * N;
+    if (e.resid) g.resid = e.resid + r0 * N;
+    g.ln_x = e.ln_x + r0 * N; g.ln_mean = e.ln_mean + r0; g.ln_rstd = e.ln_rstd + r0;
+    if (e.ln_dxb) g.ln_dxb = e.ln_dxb + r0 * N;
+    g.ln_partial = e.ln_partial + (long)gemm_ln_bwd_blocks(r0) * 3 * N;
+    const double bytes = (double)m * K * 2 + (double)N * K * 2 + (double)m * N * (4 + (e.resid ? 4 : 0) + 4 + (e.ln_dxb ? 2 : 0));
+    Traced tr(K_GEMM_LN_BWD, 2.0 * m * N * K, s, bytes);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LN_BWD>), dim3((unsigned)nt_dma_grid(m)), dim3(448), (size_t)GD_LDS, s,
+                       (const bf16*)A + r0 * lda, lda, (const bf16*)W, ldw, m, N, K, g);
+    if (hipError_t err = hipGetLastError(); err != hipSuccess) return err;
+  }
+  return hipSuccess;
 }
 
 bool gemm_res_ln_supported(long M, int N, int K, long lda, long ldw) {
@@ -1395,11 +1455,19 @@ hipError_t gemm_res_ln(const void* A, long lda, const void* W, long ldw, int M, 
   static std::atomic<unsigned long long> ready;
   if (hipError_t err = ensure_dynamic_lds((const void*)gemm_nt_dma_kernel<EPI_RES_LN>, (size_t)GD_LDS, ready); err != hipSuccess)
     return err;
-  const double bytes = (double)M * K * 2 + (double)N * K * 2 + (double)M * N * (4 + (e.resid ? 4 : 0) + 2);
-  Traced tr(K_GEMM_RES_LN, 2.0 * M * N * K, s, bytes);
-  hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_RES_LN>), dim3((unsigned)nt_dma_grid(M)), dim3(448), (size_t)GD_LDS, s,
-                     (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, e);
-  return hipGetLastError();
+  for (long r0 = 0; r0 < M; r0 += LN_SLAB_ROWS) {
+    const int m = (int)(M - r0 < LN_SLAB_ROWS ? M - r0 : LN_SLAB_ROWS);
+    GemmEpi g = e;
+    g.out0 = (float*)e.out0 + r0 * N;
+    if (e.resid) g.resid = e.resid + r0 * N;
+    g.ln_dxb = e.ln_dxb + r0 * N; g.ln_mean_out = e.ln_mean_out + r0; g.ln_rstd_out = e.ln_rstd_out + r0;
+    const double bytes = (double)m * K * 2 + (double)N * K * 2 + (double)m * N * (4 + (e.resid ? 4 : 0) + 2);
+    Traced tr(K_GEMM_RES_LN, 2.0 * m * N * K, s, bytes);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_RES_LN>), dim3((unsigned)nt_dma_grid(m)), dim3(448), (size_t)GD_LDS, s,
+                       (const bf16*)A + r0 * lda, lda, (const bf16*)W, ldw, m, N, K, g);
+    if (hipError_t err = hipGetLastError(); err != hipSuccess) return err;
+  }
+  return hipSuccess;
 }
 
 static hipError_t launch_wgrad_dma(const WgradPair& pr, int T, int slices, hipStream_t s) {
@@ -1429,10 +1497,11 @@ static hipError_t launch_wgrad_dma(const WgradPair& pr, int T, int slices, hipSt
 
 hipError_t wgrad_multi(const WgradDesc* d, int n, int T, int slices, hipStream_t s) {
   if (n < 1 || n > WD_MAXN) return hipErrorInvalidValue;
-  const long lim = 1l << 31;
+  const long lim = 0x7FFFF000l;   // per token slice (the kernel re-bases its resources at the slice's first token)
+  const long slice_tokens = (long)(((T + W_BT - 1) / W_BT + slices - 1) / slices) * W_BT;
   WgradPair pr{};
   for (int i = 0; i < n; ++i) {
-    if ((long)T * d[i].ldp * 2 >= lim || (long)T * d[i].ldq * 2 >= lim) return hipErrorInvalidValue;
+    if (slice_tokens * d[i].ldp * 2 >= lim || slice_tokens * d[i].ldq * 2 >= lim) return hipErrorInvalidValue;
     pr.p[i] = WgradOne{(const bf16*)d[i].Pm, d[i].ldp, (const bf16*)d[i].Qm, d[i].ldq, d[i].slab, d[i].P, d[i].Q, d[i].ones};
   }
   pr.n = n;
@@ -1444,8 +1513,8 @@ hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, 
   const int ntiles = (T + W_BT - 1) / W_BT;
   const int tps = (ntiles + slices - 1) / slices;
   const bf16* Pb = (const bf16*)Pm;
-  const long lim = 1l << 31;
-  if (!q_f32 && (long)T * ldp * 2 < lim && (long)T * ldq * 2 < lim) {
+  const long lim = 0x7FFFF000l;   // per token slice (the kernel re-bases its resources at the slice's first token)
+  if (!q_f32 && (long)tps * W_BT * ldp * 2 < lim && (long)tps * W_BT * ldq * 2 < lim) {
     // bf16 operands: asynchronous global->LDS pipeline
     WgradPair pr{};
     pr.p[0] = WgradOne{Pb, ldp, (const bf16*)Qm, ldq, slab, P, Q, ones};

@@ -103,8 +103,10 @@ struct Traced {  // brackets one launch
 // gemm.hip
 hipError_t gemm_nt(int epi, int a_f32, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                    GemmEpi e, hipStream_t s);
+long long gemm_general_launches();   // launches of the general (register-staged) product kernel since load
 // dx = dres + LN'(A W^T): the data-gradient product that ends a sublayer's backward with the LayerNorm backward
-// as its epilogue.  Supported: bf16 A, N <= 224 with N % 4 == 0, K >= 128, operands below 2 GiB.
+// as its epilogue.  Supported: bf16 A, N <= 224 with N % 4 == 0, K >= 128, lda <= 2340 (any M: tall inputs run as
+// row slabs of 458,752 rows).
 bool gemm_ln_bwd_supported(long M, int N, int K, long lda, long ldw);
 int gemm_ln_bwd_blocks(long M);
 hipError_t gemm_ln_bwd(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s);
@@ -114,8 +116,8 @@ bool gemm_res_ln_supported(long M, int N, int K, long lda, long ldw);
 hipError_t gemm_res_ln(const void* A, long lda, const void* W, long ldw, int M, int N, int K, GemmEpi e, hipStream_t s);
 hipError_t wgrad(const void* Pm, long ldp, const void* Qm, long ldq, int q_f32, int ones, int T, int P, int Q,
                  int slices, float* slab, hipStream_t s);
-// up to four weight gradients over the same T tokens in one launch (bf16 operands, each below 2 GiB), slice partials
-// left in each product's slab
+// up to four weight gradients over the same T tokens in one launch (bf16 operands; each token slice below 2 GiB),
+// slice partials left in each product's slab
 struct WgradDesc { const void* Pm; long ldp; const void* Qm; long ldq; float* slab; int P, Q, ones; };
 hipError_t wgrad_multi(const WgradDesc* d, int n, int T, int slices, hipStream_t s);
 hipError_t wgrad_reduce(const float* slab, int S, int P, int Q, float* grad, float* bias, int trans, int accumulate,

@@ -295,8 +295,9 @@ def wgrad(pm: torch.Tensor, qm: torch.Tensor, grad: torch.Tensor, bias_grad, tra
 
 
 def wgrad_multi_supported(*mats) -> bool:
-    """the shared launch needs bf16 operands with contiguous last dimension, each below 2 GiB"""
-    return all(m.dtype == BF16 and m.stride(1) == 1 and m.shape[0] * m.stride(0) * 2 < (1 << 31) for m in mats)
+    """the shared launch needs bf16 operands with contiguous last dimension (any number of tokens: the kernel
+    addresses each token slice from the slice's own first row)"""
+    return all(m.dtype == BF16 and m.stride(1) == 1 for m in mats)
 
 
 def wgrad_multi(products, accumulate: bool, defer: Optional[list] = None):

@@ -181,3 +181,42 @@ def test_window_gradients_match_micro_step_gradients(mods):
             worst = (k, rel)
         assert rel <= 1e-4, f"{k}: {rel:.3e}"
     print(f"worst relative L2 between window and micro-step gradients: {worst}")
+
+
+@pytest.mark.parametrize("cells", [48, 96])
+def test_large_windows_cross_the_2gib_line_on_the_fast_kernels(mods, cells):
+    """48 and 96 cells of 16,906 genes in one launch chain: the fused q/k/v tensor is 3.1 / 6.2 GB, the FeedForward
+    activations 1.35 / 2.7 GB each -- beyond what one 32-bit-addressed window covers.  Logits must carry the bits of
+    the same cells run 3 at a time (stabiliser groups of 3), every parameter gradient must equal the sum of the
+    3-cell gradients up to f32 summation order, and no product may have left the asynchronous-copy kernels."""
+    ops, s1, train = mods
+    from scmomer_amd._lib import lib
+    n, g = 16906, 3
+    m = _model(n, depth=1).train()
+    torch.manual_seed(20 + cells)
+    tok = torch.randint(0, 6, (cells, n), device=DEV)
+    labels = tok.clone()
+    labels[torch.rand((cells, n), device=DEV) > 0.15] = 6
+    params = [p for p in m.parameters() if p.requires_grad]
+    before = lib.scm_gemm_general_launches()
+    m.performer.stabiliser_group_cells = g
+    logits = m(tok)
+    loss = s1.masked_cross_entropy(logits, labels, 6, group_cells=g)
+    grads = torch.autograd.grad(loss, params, grad_outputs=torch.ones_like(loss))
+    m.performer.stabiliser_group_cells = None
+    assert lib.scm_gemm_general_launches() == before, "a product fell back to the general kernel"
+    logits = logits.detach()
+    sums = [torch.zeros_like(p, dtype=torch.float64) for p in params]
+    for lo in range(0, cells, g):
+        lg = m(tok[lo:lo + g])
+        l1 = s1.masked_cross_entropy(lg, labels[lo:lo + g].contiguous(), 6)
+        assert torch.equal(lg.detach(), logits[lo:lo + g]), f"cells {lo}..{lo + g - 1}"
+        assert torch.equal(l1.detach(), loss[lo // g].detach())
+        for acc, gr in zip(sums, torch.autograd.grad(l1, params)):
+            acc += gr.double()
+    worst = 0.0
+    for (name, _), acc, gr in zip([(k, p) for k, p in m.named_parameters() if p.requires_grad], sums, grads):
+        rel = float((gr.double() - acc).norm() / acc.norm())
+        worst = max(worst, rel)
+        assert rel <= 1e-5, f"{name}: {rel:.3e}"
+    print(f"{cells} cells: worst relative L2 of a parameter gradient against the sum over 3-cell runs: {worst:.2e}")
