@@ -303,7 +303,9 @@ int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int
 /* Accuracy of the S1 loop (s1_pretrain_rna.py:308-312): per cell b, counts[b] = {number of positions with
  * label != pad_id whose prediction 1 + argmax(logits[b,n,1:C-1]) equals the label, number of such positions}
  * (int32 [B,2]) and ratio[b] = correct / counted (f32 [B]; nan when nothing is counted).  logits f32 [B,N,C].
- * ws: int32 [B] of scratch (arrival counters); counts and ws are cleared by the call. */
+ * ws: scm_s1_accuracy_ws_ints(B, N) int32 of scratch (per-workgroup partial counts, summed in a fixed order by a
+ * second small launch; nothing needs clearing between calls). */
+int64_t scm_s1_accuracy_ws_ints(int B, int N);
 int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, int64_t pad_id, float* ratio,
                     int* counts, int* ws, void* stream);
 

@@ -91,6 +91,7 @@ SIGNATURES = {
     "scm_s1_mask": (i32, [vp, vp, vp, i32, i32, C.c_float, C.c_float, i32, i64, i64, vp, vp, vp]),
     "scm_ce_ws_floats": (i64, [i64, i64]),
     "scm_ce_groups": (i64, [i64, i64]),
+    "scm_s1_accuracy_ws_ints": (i64, [i32, i32]),
     "scm_s1_accuracy": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp]),
     "scm_bin_max_genes": (i32, []),
     "scm_bin_csr": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]),

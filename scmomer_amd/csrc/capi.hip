@@ -517,6 +517,8 @@ int scm_ce_bwd(const float* logits, const int64_t* labels, int64_t T, int C, int
   return 0;
 }
 
+int64_t scm_s1_accuracy_ws_ints(int B, int N) { return (B > 0 && N > 0) ? 2 * (int64_t)B * s1_accuracy_chunks(N) : 0; }
+
 int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, int64_t pad_id, float* ratio,
                     int* counts, int* ws, void* stream) {
   SCM_REQ(logits && labels && ratio && counts && ws, "scm_s1_accuracy: null pointer");

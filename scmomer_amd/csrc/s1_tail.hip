@@ -215,14 +215,14 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 
 // ------------------------------------------------------------------------------------------
 // accuracy of the S1 loop (s1_pretrain_rna.py:308-312): prediction = 1 + argmax over the classes 1..C-2 (the
-// first maximum wins, as torch.argmax), counted where label != pad.  grid (chunks, cells): integer atomics into
-// counts[cell] = {correct, counted} (zeroed by the launcher); the workgroup that arrives last for a cell writes
-// ratio[cell] = correct / counted (nan for a cell with nothing masked).
+// first maximum wins, as torch.argmax), counted where label != pad.  grid (chunks, cells): every workgroup leaves
+// its (correct, counted) pair in ws[cell][chunk]; a second small launch adds a cell's pairs up in chunk order and
+// writes counts[cell] and ratio[cell] = correct / counted (nan for a cell with nothing masked).  No atomics and
+// nothing to clear between calls: the result does not depend on what the buffers held before.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void s1_accuracy_kernel(const float* __restrict__ logits,
                                                           const int64_t* __restrict__ labels, int N, int C,
-                                                          long long pad_id, float* __restrict__ ratio,
-                                                          int* __restrict__ counts, int* __restrict__ arrivals) {
+                                                          long long pad_id, int* __restrict__ ws) {
   __shared__ int rc[4], rn[4];
   const int cell = blockIdx.y;
   const long base = (long)cell * N;
@@ -246,33 +246,31 @@ __global__ __launch_bounds__(256) void s1_accuracy_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) { rc[w] = correct; rn[w] = counted; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&counts[2 * cell], (rc[0] + rc[1]) + (rc[2] + rc[3]));
-    atomicAdd(&counts[2 * cell + 1], (rn[0] + rn[1]) + (rn[2] + rn[3]));
-    __threadfence();
-    if (atomicAdd(&arrivals[cell], 1) == (int)gridDim.x - 1) {   // every other workgroup's adds are visible
-      const int c = atomicAdd(&counts[2 * cell], 0), n = atomicAdd(&counts[2 * cell + 1], 0);
-      ratio[cell] = (float)c / (float)n;
-    }
+    int* p = ws + 2 * ((long)cell * gridDim.x + blockIdx.x);
+    p[0] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+    p[1] = (rn[0] + rn[1]) + (rn[2] + rn[3]);
   }
 }
 
+__global__ __launch_bounds__(64) void s1_accuracy_finalize_kernel(const int* __restrict__ ws, int chunks, int B,
+                                                                  float* __restrict__ ratio, int* __restrict__ counts) {
+  const int cell = blockIdx.x * 64 + threadIdx.x;
+  if (cell >= B) return;
+  int c = 0, n = 0;
+  for (int k = 0; k < chunks; ++k) { c += ws[2 * ((long)cell * chunks + k)]; n += ws[2 * ((long)cell * chunks + k) + 1]; }
+  counts[2 * cell] = c;
+  counts[2 * cell + 1] = n;
+  ratio[cell] = (float)c / (float)n;
+}
+
 // ---------------------------------------------------------------- host launchers
+int s1_accuracy_chunks(int N) { return (N + 255) / 256 < 64 ? (N + 255) / 256 : 64; }
 hipError_t s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, long long pad_id, float* ratio,
-                       int* counts, int* arrivals, hipStream_t s) {
+                       int* counts, int* ws, hipStream_t s) {
   Traced tr(K_CE, 0, s);
-  hipError_t e;
-  if (arrivals == counts + 2 * B) {        // one workspace (the usual case): one clear
-    e = hipMemsetAsync(counts, 0, (size_t)B * 3 * sizeof(int), s);
-    if (e != hipSuccess) return e;
-  } else {
-    e = hipMemsetAsync(counts, 0, (size_t)B * 2 * sizeof(int), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(arrivals, 0, (size_t)B * sizeof(int), s);
-    if (e != hipSuccess) return e;
-  }
-  const int chunks = (N + 255) / 256 < 64 ? (N + 255) / 256 : 64;
-  hipLaunchKernelGGL(s1_accuracy_kernel, dim3(chunks, B), dim3(256), 0, s, logits, labels, N, C, pad_id, ratio, counts,
-                     arrivals);
+  const int chunks = s1_accuracy_chunks(N);
+  hipLaunchKernelGGL(s1_accuracy_kernel, dim3(chunks, B), dim3(256), 0, s, logits, labels, N, C, pad_id, ws);
+  hipLaunchKernelGGL(s1_accuracy_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, chunks, B, ratio, counts);
   return hipGetLastError();
 }
 hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,

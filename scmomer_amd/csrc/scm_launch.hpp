@@ -181,8 +181,9 @@ hipError_t ce_fwd(const float* logits, const int64_t* labels, long T, int C, lon
                   float* partial, float* out, hipStream_t s);
 hipError_t ce_bwd(const float* logits, const int64_t* labels, long T, int C, long long ignore, long group_tokens,
                   const float* dloss, const float* loss_count, float* dlogits, hipStream_t s);
+int s1_accuracy_chunks(int N);
 hipError_t s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, long long pad_id, float* ratio,
-                       int* counts, int* arrivals, hipStream_t s);
+                       int* counts, int* ws, hipStream_t s);
 
 // ingest.hip
 constexpr int BIN_MAX_GENES = 36864;   // dense f32 row of one cell in LDS (144 KB)

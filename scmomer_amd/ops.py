@@ -535,7 +535,7 @@ def s1_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int):
     _req(labels, torch.int64, "labels")
     b, n, c = logits.shape
     ratio = torch.empty(b, dtype=F32, device=logits.device)
-    buf = torch.empty(3 * b, dtype=torch.int32, device=logits.device)
+    buf = torch.empty(2 * b + lib.scm_s1_accuracy_ws_ints(b, n), dtype=torch.int32, device=logits.device)
     counts, ws = buf[:2 * b].view(b, 2), buf[2 * b:]
     check(lib.scm_s1_accuracy(_p(logits), _p(labels), b, n, c, pad_id, _p(ratio), _p(counts), _p(ws), _stream()),
           "scm_s1_accuracy")
