@@ -85,7 +85,8 @@ def cpu_baseline(mode="train"):
     with every core this process may use: torch's own thread count, which follows OMP_NUM_THREADS / the affinity
     mask (on a shared GPU box that is this GPU's CPU share, not the machine's core count: oversubscribing a cgroup
     share slows the oracle down).  Timed: config 1 (one cell, forward, eval: 1 warm-up + 3 passes) and the metric's
-    own workload (3 cells, forward + CE + backward: 1 pass, about 24 GB of host memory), about 20 s in all.
+    own workload (3 cells, forward + CE + backward: 1 warm-up + 2 timed passes, about 24 GB of host memory), about
+    30 s in all.
     `value` is the rate of the workload the GPU line reports (train: B=3 forward+backward; extract: B=1 forward)."""
     from oracle import performer_oracle as O
     import numpy as np
@@ -113,13 +114,20 @@ def cpu_baseline(mode="train"):
     pp.update(leaves)
     labels = tokens.clone()
     labels[torch.rand(tokens.shape) > 0.15] = 6
-    t0 = time.perf_counter()
-    loss = O.masked_ce_loss(O.performer_lm_forward(tokens, pp, depth=6, heads=10), labels, 6)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    out.update(value=BATCH / dt, fwd_bwd_b3_seconds=dt,
+    times = []
+    for it in range(3):                                      # 1 warm-up pass + 2 timed passes
+        for v in leaves.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        loss = O.masked_ce_loss(O.performer_lm_forward(tokens, pp, depth=6, heads=10), labels, 6)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        del loss
+    dt = sum(times[1:]) / 2
+    out.update(value=BATCH / dt, fwd_bwd_b3_seconds=dt, fwd_bwd_b3_warmup_seconds=times[0],
                sample=f"config 2's workload: 3 cells (B=3), forward + CE + backward at 16906 tokens, fp32 torch-CPU "
-                      f"oracle, 1 timed pass ({dt:.1f} s); config 1 (B=1 forward, eval): {fwd:.2f} s per cell")
+                      f"oracle, 1 warm-up + 2 timed passes ({dt:.1f} s each); config 1 (B=1 forward, eval): "
+                      f"{fwd:.2f} s per cell")
     return out
 
 
@@ -393,15 +401,13 @@ def _say(msg):
 
 
 def launch_ranks(args) -> int:
-    """`python bench.py --gpus N` started directly (no torchrun): this process stays off the GPU, starts N copies of
-    itself as ranks 0..N-1 (one per GPU, env:// rendezvous on 127.0.0.1, the layout torchrun would give them),
+    """`python bench.py --gpus N` started directly (no torchrun): this process never touches the GPU runtime (it does
+    not even count devices: a rank that finds no device of its own says so and exits non-zero), starts N copies
+    of itself as ranks 0..N-1 (one per GPU, env:// rendezvous on 127.0.0.1, the layout torchrun would give them),
     waits for all of them and relays rank 0's JSON line.  Returns the exit code."""
     import socket
     import subprocess
     n = args.gpus
-    if os.environ.get("SCM_BENCH_ONE_DEVICE") != "1" and torch.cuda.device_count() < n:
-        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
-        return 2
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -409,6 +415,9 @@ def launch_ranks(args) -> int:
     for r in range(n):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), RANK=str(r),
                    LOCAL_RANK=str(r))
+        # RCCL shares device buffers between the ranks of a node through IPC handles; hosts whose driver only offers
+        # dmabuf handles need the legacy mode off, or hipIpcGetMemHandle fails with "invalid argument".  An
+        # environment that already sets the variable keeps its value.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
@@ -445,6 +454,9 @@ def main():
     # replaces RCCL, which refuses two ranks on one device.  Never set by the driver.
     if os.environ.get("SCM_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but only {torch.cuda.device_count()} GPU(s) "
+                         f"are visible (--gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist

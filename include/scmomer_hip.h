@@ -92,7 +92,9 @@ int scm_ln_bwd(const float* dy, const float* x, const float* mean, const float* 
  * D % 4 == 0 as above, any T (the partial count is capped at 1024 workgroups); a size beyond the array is rejected
  * with SCM_EINVAL.  The first call on a device looks the array's address up (make that call outside a graph
  * capture).  All calls on one GPU share the array: calls that overlap on one GPU (different streams) race; calls
- * on one stream are ordered and safe.  Results are bit-identical to scm_ln_bwd's. */
+ * on one stream are ordered and safe.  The stream must belong to the CURRENT device (each GPU has its own copy of
+ * the array at its own address, and the current device's is used): a stream of another device is rejected with
+ * SCM_EINVAL.  Results are bit-identical to scm_ln_bwd's. */
 int scm_ln_bwd_noalloc(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* dres, int64_t T, int D, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
                        float* dres_colsum, int accumulate, void* stream);

@@ -170,6 +170,14 @@ int scm_ln_bwd_noalloc(const float* dy, const float* x, const float* mean, const
   SCM_REQ((int64_t)ln_bwd_blocks(T) * 3 * D <= LN_STATIC_SCRATCH_FLOATS,
           "scm_ln_bwd_noalloc: T=%lld, D=%d need more than the built-in scratch of %d floats", (long long)T, D,
           LN_STATIC_SCRATCH_FLOATS);
+  // every GPU holds its own copy of the array at its own address: the address looked up below is the current
+  // device's, so the stream must belong to the current device
+  int cur = -1;
+  hipDevice_t sdev = -1;
+  SCM_HIP(hipGetDevice(&cur), "scm_ln_bwd_noalloc(current device)");
+  SCM_HIP(hipStreamGetDevice((hipStream_t)stream, &sdev), "scm_ln_bwd_noalloc(stream's device)");
+  SCM_REQ((int)sdev == cur, "scm_ln_bwd_noalloc: the stream belongs to device %d but device %d is current: make the "
+          "stream's device current before the call", (int)sdev, cur);
   float* ws = nullptr;
   SCM_HIP(ln_bwd_static_scratch(&ws), "scm_ln_bwd_noalloc(scratch address)");
   return scm_ln_bwd(dy, x, mean, rstd, gamma, dres, T, D, dx, dx_bf16, ws, dgamma, dbeta, dres_colsum, accumulate,

@@ -178,10 +178,14 @@ SCM_DEV u32x4 dma_rsrc(const void* p, uint32_t bytes) {
 SCM_DEV uint32_t lds_addr_of(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
+// (M0, a reserved register, is named as clobbered on purpose: the diagnostic about that is silenced for this helper only)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 SCM_DEV void dma16_to_lds(u32x4 rsrc, uint32_t lds_wave_base, uint32_t voffset, uint32_t soffset) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :: "s"(lds_wave_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 // s_waitcnt vmcnt(N) only (expcnt/lgkmcnt left alone): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4]<<14
 template <int N>
 SCM_DEV void wait_vmcnt() {

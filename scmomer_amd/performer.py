@@ -491,14 +491,23 @@ class PerformerLM(nn.Module):
         The embedding kernel cannot raise from the device: it looks such a token up as token 0 and sets a flag.
         This call reads the flag (it synchronises with the device: use it where the host waits anyway, e.g. at the
         end of an epoch), clears it and raises IndexError when any forward since the last check saw a bad id."""
+        if self.pop_bad_token_flag():
+            raise IndexError(self.bad_token_message())
+
+    def bad_token_message(self) -> str:
+        return (f"token id outside [0, {self.token_emb.num_embeddings}) reached the embedding "
+                "(negative or NaN expression values, or a wrong class_limit)")
+
+    def pop_bad_token_flag(self) -> bool:
+        """Read and clear the bad-token flag without raising (synchronises with the device): data-parallel drivers
+        combine it over the ranks first, so that every rank raises together instead of one rank leaving its peers
+        blocked in the next collective."""
         bad = False
         for flag in self.__dict__.get("_scm_token_err", {}).values():
             if int(flag.item()):
                 flag.zero_()
                 bad = True
-        if bad:
-            raise IndexError(f"token id outside [0, {self.token_emb.num_embeddings}) reached the embedding "
-                             "(negative or NaN expression values, or a wrong class_limit)")
+        return bad
 
     def forward(self, x, return_encodings=False, output_attentions=False, **kwargs):
         b, n = x.shape

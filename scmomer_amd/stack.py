@@ -10,6 +10,7 @@ encoders stop early: s1_pretrain_rna.py:223-228, s2_pretrain_multimodal.py:234-2
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -429,40 +430,43 @@ def _flat_params(spec: StackSpec) -> List[torch.Tensor]:
 # --------------------------------------------------------------------------------------------
 # gradient sink: parameter gradients written straight into a caller's accumulators
 # --------------------------------------------------------------------------------------------
-_SINK: Optional[Dict[int, torch.Tensor]] = None     # id(parameter) -> f32 accumulator of the parameter's shape
+_TLS = threading.local()     # .sink: id(parameter) -> f32 accumulator of the parameter's shape, while a grad_sink is open
 
 
 class grad_sink:
-    """Context manager for a training driver that accumulates gradients over micro-steps: inside it, a backward
-    pass of the fused stack ADDS every parameter gradient whose final reduction it can redirect into accs[i] (the
-    last launch of the backward does the add) and hands None back to autograd for that parameter, instead of
-    materialising the gradient for the caller to add.  Gradients it cannot redirect are returned as usual.  The
-    backward runs on autograd's device thread, so the table is process-wide, not thread-local: one driver at a time."""
+    """Context manager for a training driver that accumulates gradients over micro-steps.  A forward pass of the
+    fused stack run inside it remembers the table (on its autograd context), and its backward pass -- whichever
+    thread autograd runs it on, inside the context or after it -- ADDS every parameter gradient whose final
+    reduction it can redirect into accs[i] (the last launch of the backward does the add) and hands None back to
+    autograd for that parameter, instead of materialising the gradient for the caller to add.  Gradients it cannot
+    redirect are returned as usual.  The table is thread-local where it is looked up (the forward, in the driver's
+    own thread): drivers on different threads, or nested ones, do not see each other's accumulators."""
 
     def __init__(self, params, accs):
         self.table = {id(p): a for p, a in zip(params, accs)}
+        self.before = None
 
     def __enter__(self):
-        global _SINK
-        _SINK = self.table
+        self.before = getattr(_TLS, "sink", None)
+        _TLS.sink = self.table
         return self
 
     def __exit__(self, *exc):
-        global _SINK
-        _SINK = None
+        _TLS.sink = self.before
         return False
 
 
-def _redirect_jobs(jobs: list, grads: Dict[Tuple[int, str], torch.Tensor], byname: Dict[Tuple[int, str], Any]) -> set:
+def _redirect_jobs(jobs: list, grads: Dict[Tuple[int, str], torch.Tensor], byname: Dict[Tuple[int, str], Any],
+                   sink: Dict[int, torch.Tensor]) -> set:
     """Point the deferred reductions at the sink's accumulators where that is exact: every output of a job must be
     covered by gradient tensors whose accumulators sit at the same relative offsets (the fused q/k/v weight gradient
     is one [3*inner, D] output: its three accumulators must be adjacent).  Returns the names now accumulated in place."""
     sunk: set = set()
-    if not _SINK:
+    if not sink:
         return sunk
     spans = []                                       # (gradient pointer, bytes, name, accumulator)
     for nm, gt in grads.items():
-        acc = _SINK.get(id(byname.get(nm)))
+        acc = sink.get(id(byname.get(nm)))
         spans.append((gt.data_ptr(), gt.numel() * 4, nm, acc if (acc is not None and gt.is_contiguous() and
                                                                  acc.is_contiguous() and acc.dtype == F32 and
                                                                  acc.numel() == gt.numel()) else None))
@@ -488,6 +492,8 @@ def _redirect_jobs(jobs: list, grads: Dict[Tuple[int, str], torch.Tensor], bynam
             plan.append((k, base[3].data_ptr()))
             names += [sp[2] for sp in members]
         if ok and plan:
+            # accumulate applies to the whole job: every output it writes must have been redirected
+            assert len(plan) == sum(1 for o in j.out if o), "a reduction job with an output outside the sink"
             for k, ptr in plan:
                 j.out[k] = ptr
             j.accumulate = 1
@@ -530,6 +536,7 @@ class _StackFn(torch.autograd.Function):
             tapes.append((at, ft))
             x = x2
         ctx.spec, ctx.tapes, ctx.tokens = spec, tapes, tokens
+        ctx.sink = getattr(_TLS, "sink", None)               # the driver's accumulators, if a grad_sink is open
         if spec.norm_w is None:
             ctx.head = None
             return x
@@ -620,7 +627,7 @@ class _StackFn(torch.autograd.Function):
                     grads[(-1, "token_emb")] = ge
             else:
                 d_inp = dx.view(ctx.tapes[0][0].shape) if nl else dx
-        sunk = _redirect_jobs(jobs, grads, dict(zip(spec.names, _flat_params(spec)))) if _SINK else set()
+        sunk = _redirect_jobs(jobs, grads, dict(zip(spec.names, _flat_params(spec))), ctx.sink) if ctx.sink else set()
         ops.reduce_batch(jobs)
         out_grads = []
         for i, nm in enumerate(spec.names):

@@ -285,42 +285,43 @@ class S1Trainer:
             raise ValueError(f"a window of {groups} micro-batches needs a multiple of {groups} cells, got {data.shape[0]}")
         b = data.shape[0] // groups
         performer = getattr(self.model, "performer", None)
-        if groups == 1:
-            masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
-            logits = self.model(masked)
-            raw = self.loss_fn(logits, labels, self.pad_id)
-        else:
-            masked, labels = self._mask_window(data, groups)
-            if performer is not None:
-                before = performer.stabiliser_group_cells
-                performer.stabiliser_group_cells = b        # one key stabiliser per micro-batch
-            try:
+        # The encoder's backward adds its gradients into the accumulators itself (its last launch, the batched
+        # reductions, does the add): the forward run inside grad_sink remembers them.  What autograd hands back are
+        # the gradients of anything outside the fused stack.
+        from . import stack
+        with stack.grad_sink(self.params, self.accs):
+            if groups == 1:
+                masked, labels = self.mask_fn(data, self.mask_prob, self.replace_prob, self.pad_id, self.mask_id)
                 logits = self.model(masked)
-            finally:
-                if performer is not None:
-                    performer.stabiliser_group_cells = before
-            if self.loss_fn is _device_loss:
-                raw = s1.masked_cross_entropy(logits, labels, self.pad_id, group_cells=b)
+                raw = self.loss_fn(logits, labels, self.pad_id)
             else:
-                raw = torch.stack([self.loss_fn(logits[g * b:(g + 1) * b], labels[g * b:(g + 1) * b], self.pad_id)
-                                   for g in range(groups)])
-        loss = raw / self.grad_acc
-        if self.params:
-            # autograd.grad hands the gradients back without going through the parameters' AccumulateGrad nodes (which
-            # are tied to the stream they were created on: recording this step on a side stream would mix streams).
-            # The backward starts from the unscaled losses with 1/grad_acc as the seed of each: the value the
-            # division's own backward would pass on (1.0 * 1/grad_acc), without its two small kernels.
-            key = (raw.device, groups)
-            if key not in self._seeds:
-                self._seeds[key] = torch.full(raw.shape, 1.0, dtype=raw.dtype, device=raw.device) / self.grad_acc
-            # the encoder's backward adds its gradients into the accumulators itself (its last launch, the batched
-            # reductions, does the add); what it hands back are the gradients of anything outside the fused stack
-            from . import stack
-            with stack.grad_sink(self.params, self.accs):
+                masked, labels = self._mask_window(data, groups)
+                if performer is not None:
+                    before = performer.stabiliser_group_cells
+                    performer.stabiliser_group_cells = b        # one key stabiliser per micro-batch
+                try:
+                    logits = self.model(masked)
+                finally:
+                    if performer is not None:
+                        performer.stabiliser_group_cells = before
+                if self.loss_fn is _device_loss:
+                    raw = s1.masked_cross_entropy(logits, labels, self.pad_id, group_cells=b)
+                else:
+                    raw = torch.stack([self.loss_fn(logits[g * b:(g + 1) * b], labels[g * b:(g + 1) * b], self.pad_id)
+                                       for g in range(groups)])
+            loss = raw / self.grad_acc
+            if self.params:
+                # autograd.grad hands the gradients back without going through the parameters' AccumulateGrad nodes
+                # (which are tied to the stream they were created on: recording this step on a side stream would mix
+                # streams).  The backward starts from the unscaled losses with 1/grad_acc as the seed of each: the
+                # value the division's own backward would pass on (1.0 * 1/grad_acc), without its two small kernels.
+                key = (raw.device, groups)
+                if key not in self._seeds:
+                    self._seeds[key] = torch.full(raw.shape, 1.0, dtype=raw.dtype, device=raw.device) / self.grad_acc
                 grads = torch.autograd.grad(raw, self.params, grad_outputs=self._seeds[key], allow_unused=True)
-            left = [(a, g) for a, g in zip(self.accs, grads) if g is not None]
-            if left:
-                torch._foreach_add_([a for a, _ in left], [g for _, g in left])
+                left = [(a, g) for a, g in zip(self.accs, grads) if g is not None]
+                if left:
+                    torch._foreach_add_([a for a, _ in left], [g for _, g in left])
         if groups == 1:
             return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
         return loss.detach(), s1_cell_accuracy(logits.detach(), labels, self.pad_id).view(groups, b).mean(dim=1)
@@ -450,10 +451,22 @@ class S1Trainer:
 
     def _check_tokens(self) -> None:
         """Bad token ids seen by the embedding kernel since the last check raise here, where the host has just
-        waited for the device anyway."""
-        check = getattr(self.model, "raise_on_bad_token", None)
-        if check is not None:
-            check()
+        waited for the device anyway (end of an epoch or of a validation pass: the optimizer steps of that epoch
+        have already used the substituted embeddings; the reference's nn.Embedding faults on the step itself).  The
+        flag is combined over the ranks first, so all ranks raise together."""
+        pop = getattr(self.model, "pop_bad_token_flag", None)
+        if pop is None:
+            return
+        bad = int(pop())
+        if self.world > 1:                                   # any rank's bad token stops every rank, at the same point
+            t = torch.tensor([bad], dtype=torch.int32)
+            if dist.get_backend(self.group) != "gloo":
+                t = t.to(next(self.model.parameters()).device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            bad = int(t.item())
+        if bad:
+            raise IndexError(self.model.bad_token_message() + (f" [seen on at least one of {self.world} ranks]"
+                                                               if self.world > 1 else ""))
 
     def train_epoch(self, batches: Iterable[torch.Tensor]) -> Tuple[float, float]:
         """s1_pretrain_rna.py:281-322 for one epoch.  -> (training loss as the reference prints it, i.e. the mean

@@ -233,7 +233,7 @@ def test_two_optimizer_steps_vs_oracle_autograd_and_adam(mods):
 
 
 def test_gradient_sink_adds_what_autograd_would_return(mods):
-    """Inside stack.grad_sink the backward adds every parameter gradient straight into the driver's accumulators
+    """A forward run inside stack.grad_sink makes its backward add every parameter gradient straight into the driver's accumulators
     (the slices of one flat bucket, as in S1Trainer) and returns None for it; the accumulators end up with the bits
     of 'materialise the gradients, then add them'."""
     ingest, s1, train = mods
@@ -253,11 +253,12 @@ def test_gradient_sink_adds_what_autograd_would_return(mods):
         for a in accs:
             a.fill_(0.125)
         masked, labels = s1.data_mask_device(tok, 0.15, 0.9, 6, 6, rand_pick=pick, rand_replace=rep)
-        loss = s1.masked_cross_entropy(m(masked), labels, 6)
         if sink:
-            with stack.grad_sink(params, accs):
-                grads = torch.autograd.grad(loss, params, allow_unused=True)
+            with stack.grad_sink(params, accs):              # the forward remembers the accumulators ...
+                loss = s1.masked_cross_entropy(m(masked), labels, 6)
+            grads = torch.autograd.grad(loss, params, allow_unused=True)   # ... wherever the backward runs
         else:
+            loss = s1.masked_cross_entropy(m(masked), labels, 6)
             grads = torch.autograd.grad(loss, params, allow_unused=True)
         returned = sum(g is not None for g in grads)
         for a, g in zip(accs, grads):

@@ -161,13 +161,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
+N_CELLS = 48
+
+
 def _worker(rank, world, port, out_dir, lr, grad_acc):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)                                # up to 8 ranks share this machine's cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model = O.standin_lm(99 + rank)                     # different replicas: rank 0's weights must win
         tr = train.S1Trainer(model, learning_rate=lr, grad_acc=grad_acc, mask_fn=_fixed_mask, loss_fn=_torch_loss)
-        tok, val = O.standin_cells(7, 12, 48), O.standin_cells(8, 5, 48)
+        tok, val = O.standin_cells(7, N_CELLS, 48), O.standin_cells(8, 5, 48)
         hist = tr.fit(tok, val, epochs=2, batch_size=2, ckpt_dir=os.path.join(out_dir, f"r{rank}"), log=lambda m: None)
         torch.save({"sd": model.state_dict(), "hist": hist}, os.path.join(out_dir, f"out{rank}.pt"))
     finally:
@@ -175,45 +179,107 @@ def _worker(rank, world, port, out_dir, lr, grad_acc):
 
 
 def _fixed_mask(data, mask_prob, replace_prob, pad_id, mask_id):
-    """draws that depend only on the cells, so that one process and two ranks mask identically"""
+    """draws that depend only on the cells, so that one process and several ranks mask identically"""
     gen = torch.Generator().manual_seed(int(data.sum()) + 17 * data.shape[0])
     return MO.data_mask_tensor(data, mask_prob, replace_prob, pad_id, mask_id, rand_pick=torch.rand(data.shape, generator=gen),
                         rand_replace=torch.rand(data.shape, generator=gen))
 
 
-def test_two_ranks_match_one_process_with_both_shards(tmp_path):
-    """world_size 2 over gloo: replicas end identical; the weights equal those of one process that runs both
-    ranks' micro-batches itself and averages (gradient mean over ranks == DDP)"""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ranks_match_one_process_with_all_shards(tmp_path, world):
+    """world_size 2, 4 and 8 over gloo (the S1 driver as one process per GPU runs it, s1_pretrain_rna.py:75-82,242):
+    replicas end identical; the weights equal those of one process that runs every rank's micro-batches itself and
+    averages (gradient mean over ranks == DDP); reported accuracies are percentages"""
     from scmomer_amd import dist as sdist
-    lr, grad_acc, world = 0.02, 3, 2
+    lr, grad_acc = 0.02, 3
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), lr, grad_acc), nprocs=world, join=True)
-    o0 = torch.load(os.path.join(tmp_path, "out0.pt"), weights_only=False)
-    o1 = torch.load(os.path.join(tmp_path, "out1.pt"), weights_only=False)
-    for k in o0["sd"]:
-        assert torch.equal(o0["sd"][k], o1["sd"][k])
-    assert o0["hist"][0]["train_loss"] == o1["hist"][0]["train_loss"]
-    assert o0["hist"][1]["val_acc"] == o1["hist"][1]["val_acc"]
+    outs = [torch.load(os.path.join(tmp_path, f"out{r}.pt"), weights_only=False) for r in range(world)]
+    for o in outs[1:]:
+        for k in outs[0]["sd"]:
+            assert torch.equal(outs[0]["sd"][k], o["sd"][k])
+        assert outs[0]["hist"][0]["train_loss"] == o["hist"][0]["train_loss"]
+        assert outs[0]["hist"][1]["val_acc"] == o["hist"][1]["val_acc"]
+    for h in outs[0]["hist"]:
+        assert 0.0 <= h["train_acc"] <= 100.0 and 0.0 <= h["val_acc"] <= 100.0
     assert os.path.exists(os.path.join(tmp_path, "r0", "pretrain_rna.pth"))
     assert not os.path.exists(os.path.join(tmp_path, "r1"))            # only the master writes checkpoints
 
-    # one process: per optimizer step, the mean over both ranks' accumulated gradients
+    # one process: per optimizer step, the mean over all ranks' accumulated gradients
     model = O.standin_lm(99)
-    tok = O.standin_cells(7, 12, 48)
+    tok = O.standin_cells(7, N_CELLS, 48)
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     sch = train.CosineAnnealingWarmupRestarts(opt, first_cycle_steps=15, cycle_mult=2, max_lr=lr, min_lr=1e-6,
                                               warmup_steps=5, gamma=0.9)
+    steps = 0
+    micro = 0                                               # the driver's micro-step counter restarts every epoch
     for epoch in (1, 2):
         shards = [sdist.sampler_indices(len(tok), r, world, epoch=epoch) for r in range(world)]
         nb = len(shards[0]) // 2
+        micro = 0
         for b in range(nb):
             for r in range(world):
                 data = tok[shards[r][2 * b:2 * b + 2]]
                 mi, lab = _fixed_mask(data, 0.15, 0.9, 6, 6)
                 (_torch_loss(model(mi), lab, 6) / grad_acc / world).backward()
-            if (b + 1) % grad_acc == 0:
+            micro += 1
+            if micro % grad_acc == 0:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), 100)
                 opt.step()
                 opt.zero_grad()
+                steps += 1
         sch.step()
+    assert steps >= 2                                       # every world size takes optimizer steps in this run
     for k, v in model.state_dict().items():
-        torch.testing.assert_close(o0["sd"][k], v, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(outs[0]["sd"][k], v, rtol=1e-5, atol=1e-6)
+
+
+def test_window_step_equals_micro_steps_on_the_host_formulation(g):
+    """window_step over 3 stacked micro-batches == 3 micro_step calls (stand-in model, torch masking and loss):
+    same losses and accuracies per micro-batch, same accumulated gradients, same weights after the optimizer step;
+    a window that would straddle the optimizer step is refused"""
+    tok = O.standin_cells(7, 18, 64)
+    outs = []
+    for window in (1, 3):
+        model = O.standin_lm(99)
+        tr = train.S1Trainer(model, learning_rate=0.01, grad_acc=3, mask_fn=_fixed_mask, loss_fn=_torch_loss, window=window)
+        tr.scheduler.step(), tr.scheduler.step()
+        losses, accs = [], []
+        for w in range(2):
+            batch = [tok[6 * w + 2 * i:6 * w + 2 * i + 2] for i in range(3)]
+            if window == 1:
+                for b in batch:
+                    l_, a_ = tr.micro_step(b)
+                    losses.append(l_.reshape(1)), accs.append(a_.reshape(1))
+            else:
+                l_, a_ = tr.window_step(torch.cat(batch))
+                assert tuple(l_.shape) == (3,)
+                losses.append(l_), accs.append(a_)
+        assert tr.index == 6
+        outs.append((torch.cat(losses), torch.cat(accs), model.state_dict()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=0)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-6, atol=0)
+    for k, v in outs[0][2].items():
+        torch.testing.assert_close(outs[1][2][k], v, rtol=1e-5, atol=1e-7)
+    tr = train.S1Trainer(O.standin_lm(99), learning_rate=0.01, grad_acc=4, mask_fn=_fixed_mask, loss_fn=_torch_loss, window=2)
+    tr.micro_step(tok[:2])
+    tr.window_step(torch.cat([tok[2:4], tok[4:6]]))
+    with pytest.raises(ValueError):
+        tr.window_step(torch.cat([tok[6:8], tok[8:10]]))    # micro-steps 4 and 5: the optimizer step lies between
+    with pytest.raises(ValueError):
+        train.S1Trainer(O.standin_lm(99), grad_acc=5, mask_fn=_fixed_mask, loss_fn=_torch_loss, window=2)
+
+
+def test_train_epoch_runs_windows_and_the_ragged_tail_one_by_one(g):
+    """train_epoch with window 2 over 7 batches (the last one smaller): three windows, then the tail as micro-steps;
+    the epoch's numbers equal those of the same epoch run one micro-step at a time"""
+    tok = O.standin_cells(7, 20, 64)
+    res = []
+    for window in (1, 2):
+        model = O.standin_lm(99)
+        tr = train.S1Trainer(model, learning_rate=0.01, grad_acc=2, mask_fn=_fixed_mask, loss_fn=_torch_loss, window=window)
+        tr.scheduler.step()
+        res.append((tr.train_epoch(tr.batches_of(tok, 3, 1)), tr.index, model.state_dict()))
+    assert res[0][1] == res[1][1] == 7
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)
+    for k, v in res[0][2].items():
+        torch.testing.assert_close(res[1][2][k], v, rtol=1e-5, atol=1e-7)
