@@ -317,7 +317,10 @@ int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, in
  * column indices of a row add up).  Cell b of the batch is row rows[b] (rows == NULL: row b).  tokens int64 [B,N].
  * rule 0: v > limit -> limit, then truncation toward zero; rule 1: round half to even, clamp to [0, limit].
  * *err_flag (device int, caller zeroes it) gets bit 0 for a row index outside [0,n_rows) and bit 1 for a column
- * index outside [0,N); such entries are skipped.  N <= scm_bin_max_genes() (the dense row is built in LDS). */
+ * index outside [0,N); such entries are skipped.  N <= scm_bin_max_genes() (the dense row is built in LDS).
+ * Bit-exact with the reference's bins for canonical CSR (no duplicate column in a row) and for pairs of
+ * duplicates; with three or more duplicates of one gene their f32 sum is taken in another order than scipy's
+ * toarray(), which can move a value across a bin edge by one ulp. */
 int scm_bin_max_genes(void);
 int scm_bin_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows,
                 int64_t n_rows, int B, int N, int rule, int limit, int64_t* tokens, int* err_flag, void* stream);

@@ -844,7 +844,7 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
         for (int j = 0; j < 8; ++j) dof[ks][j] = (bf16)((float)dof[ks][j] * inv);
       const float off = (HALF_C2 * norm2 + CNORM * rmx) * LOG2E;
       f32x16 Y[2] = {zero16(), zero16()};
-      float rs = 0.f, rsm = 0.f;
+      float rs = 0.f;
       int jstar = 1 << 20;
       auto tile = [&](int t, auto last_c) {
         constexpr bool LAST = decltype(last_c)::value;
@@ -870,15 +870,11 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
             if (LAST) e = fv ? e : 0.f;
             const float v = e * (G[r] + z4[i] * dden);
             rs += v;
-            // The stabiliser routes -sum(dA) to the arg-max feature j*, so dA[j*] Omega[j*] cancels
-            // against it exactly: keep that (largest) element out of the bf16 product and apply the
-            // net coefficient -(sum of the other dA) in f32 at the write-back.  Rows are visited downwards,
-            // so the last assignment to jr is the smallest matching row.
+            dA[r] = v;
+            // where the row max sits (the stabiliser's gradient goes there, see below).  Rows are visited
+            // downwards, so the last assignment to jr is the smallest matching row.
             const bool ismax = fv && X[r] == rmx;
             jr = ismax ? acc_row(r, 0) : jr;
-            const float vm = ismax ? 0.f : v;
-            dA[r] = vm;
-            rsm += vm;
           }
         }
         jstar = (jr < 64 && jstar >= (1 << 20)) ? 32 * t + jr + 4 * half : jstar;
@@ -892,9 +888,31 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
 #pragma unroll 2
       for (int t = 0; t < NFT - 1; ++t) tile(t, std::false_type{});
       tile(NFT - 1, std::true_type{});
-      const float ddiag = -xhalf_sum(rs);
-      const float stabc = -xhalf_sum(rsm);
+      const float rs_all = xhalf_sum(rs);
+      const float ddiag = -rs_all;
       jstar = min(jstar, __shfl_xor(jstar, 32));
+      // The stabiliser routes -sum(dA) to the arg-max feature j*: the net coefficient of Omega[j*] is
+      // dA[j*] - sum(dA) = -(sum of the other dA), a difference that must not be left to bf16.  The matrix product
+      // above carried bf16(dA[j*]) Omega[j*]; dA[j*] itself is recomputed here in f32 from its factors (the
+      // exponential at the row max, the context row j* against this token's dO/den, z[j*]), and the write-back adds
+      // (dA[j*] - bf16(dA[j*]) - sum(dA)) Omega[j*] in f32.
+      float stabc = 0.f;
+      if (jstar < NF) {
+        float gs = 0.f;
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        struct Pairs { bf16x2_t p[4]; };   // a fragment's 16 bytes as four packed pairs (no element extraction)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const Pairs cr = __builtin_bit_cast(Pairs, *(const bf16x8*)(mim + img_off(jstar, 16 * ks + 8 * half)));
+          const Pairs dd = __builtin_bit_cast(Pairs, dof[ks]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gs = __builtin_amdgcn_fdot2_f32_bf16(cr.p[j], dd.p[j], gs, false);
+        }
+        gs = xhalf_sum(gs);
+        const float da = exp2_fast(rmx * (CNORM * LOG2E) - off) * (gs + zv[jstar] * dden);
+        stabc = (da - (float)(bf16)da) - rs_all;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the next tile's loads stay below: hoisted above, they cost spills
       bf16x8 xr[4];
       load_x_rows(xr, rx, a.x.sn, n0, n_hi);
       fetch(n0 + TRIP, nxf, nyf, ny2f, nden, nrmx);

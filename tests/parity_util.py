@@ -22,6 +22,12 @@ import torch
 RTOL = 1e-2
 ATOL_RMS_ACT = 4e-2      # logits, encodings, attention / layer outputs   (largest measured: 2.1e-2)
 ATOL_RMS_GRAD = 1.6e-1   # parameter and input gradients                  (largest measured: 8.6e-2)
+# Whole-tensor summaries of the same tolerance, for tests that compare a model's outputs and gradients tensor by
+# tensor (they follow from the elementwise bound for tensors without heavy tails; asserted on their own because a
+# uniform drift of 1 % would pass the elementwise bound through its relative part):
+REL_MAX_ACT = 6e-3       # max |got - ref| / max |ref| of logits / encodings        (largest measured: 3.1e-3)
+REL_L2_ACT = 4e-3        # relative L2 error of logits / encodings                  (largest measured: 1.5e-3)
+REL_L2_GRAD = 3e-2       # relative L2 error of a parameter gradient tensor         (largest measured: 1.1e-2)
 
 
 def _d(t):

@@ -3,10 +3,9 @@
 Against (a) the golden vectors produced by the reference itself (float32) and (b) the CPU oracle
 in float64 on seeded inputs.
 
-Stated bf16 tolerance (operands of every matrix product are bf16, accumulation and the residual
-stream are f32): logits / encodings within 6e-3 of the tensor's max magnitude elementwise and
-4e-3 in relative L2; parameter gradients within 3e-2 relative L2 per tensor (measured values are
-printed).  Token / index work (embedding gather) is bit exact and tested in test_gpu_ops.py.
+The stated bf16 tolerance is defined ONCE, in tests/parity_util.py (elementwise bound plus its whole-tensor
+summaries REL_MAX_ACT / REL_L2_ACT / REL_L2_GRAD, which this file asserts; measured values are printed).
+Token / index work (embedding gather) is bit exact and tested in test_gpu_ops.py.
 """
 import os
 
@@ -19,17 +18,7 @@ pytestmark = pytest.mark.gpu
 from oracle import performer_oracle as O  # noqa: E402
 
 DEV = "cuda"
-TOL_MAX, TOL_L2, TOL_GRAD = 6e-3, 4e-3, 3e-2
-
-
-def relmax(a, b):
-    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
-
-
-def rell2(a, b):
-    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
-    return float((a - b).norm() / (b.norm() + 1e-30))
+from parity_util import REL_L2_ACT as TOL_L2, REL_L2_GRAD as TOL_GRAD, REL_MAX_ACT as TOL_MAX, rell2, relmax  # noqa: E402
 
 
 def build(p, n, depth, head):

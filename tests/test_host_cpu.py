@@ -30,7 +30,10 @@ def test_bin_edge_values():
 
 
 @pytest.mark.parametrize("seed,n", [(0, 64), (1, 257), (2, 2000), (3, 16906)])
-def test_mask_matches_oracle_on_random_rows(seed, n):
+def test_oracle_masking_formulations_agree_and_keep_the_mask_invariants(seed, n):
+    """test infrastructure checking itself: the oracle's two formulations of data_mask (torch ops in the reference's
+    order; numpy loops) agree on random rows, and both keep the invariants of s1_pretrain_rna.py:88-121.  No
+    product code runs here: the package's masking is the device kernel (tests/test_gpu_s1_tail.py)."""
     rng = np.random.default_rng(seed)
     cells = ((rng.random((3, n)) < 0.15) * rng.gamma(2.0, 1.2, (3, n))).astype(np.float32)
     if seed == 1:

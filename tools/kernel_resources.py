@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 for src in sys.argv[1:]:
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src,
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", src,
                           "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                          capture_output=True, text=True).stderr
     cur = {}
