@@ -24,7 +24,7 @@ timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_x -o w -- python bench.py --mode extract --cells 48 --warmup 1 --no-cpu-baseline > $OUT/bench_write_x.json 2> $OUT/write_x.err || { echo "extract write pass failed"; tail -5 $OUT/write_x.err; exit 1; }
 echo "extract passes ok"
 python tools/pmc_summary.py $OUT/pmc_fetch_x $OUT/pmc_write_x > $OUT/pmc_extract_summary.txt
-python tools/prof_summary.py $OUT/trace 30 60 > $OUT/kernel_stats_summary.txt
+python tools/prof_summary.py $OUT/trace 31 60 > $OUT/kernel_stats_summary.txt
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.txt
 # keep only the summaries and the stats csv (the raw traces are large)
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
