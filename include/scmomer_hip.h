@@ -311,6 +311,30 @@ int64_t scm_s1_accuracy_ws_ints(int B, int N);
 int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, int64_t pad_id, float* ratio,
                     int* counts, int* ws, void* stream);
 
+/* ---- the optimizer step of the S1 loop: s1_pretrain_rna.py:303-305 (clip_grad_norm_(model.parameters(), 100),
+ *      optimizer.step() of the Adam built at :247, optimizer.zero_grad()) over every parameter tensor in TWO launches.
+ *      The table (DEVICE memory) lists chunks of at most scm_adam_chunk_elems() consecutive elements, each inside one
+ *      parameter tensor; the chunks of a tensor are consecutive and carry the tensor's number.  Per element, with
+ *      g = grad * grad_scale (grad_scale = 1 / world size after the gradient all-reduce):
+ *        norm = sqrt(sum over tensors of |g_tensor|^2) as torch forms it, coef = min(1, max_norm / (norm + 1e-6))
+ *               (max_norm <= 0: no clipping), g *= coef;
+ *        exp_avg += (g - exp_avg) (1 - beta1);  exp_avg_sq = exp_avg_sq beta2 + (1 - beta2) g g;
+ *        param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps);  grad = 0
+ *      i.e. torch.optim.Adam (no weight decay, no amsgrad) operation by operation; `step` is the step number AFTER
+ *      the increment (>= 1); the hyper-parameters are doubles, as torch holds them (1 - beta is formed in double).
+ *      ws: n_chunks floats.  norm_out (may be NULL): the total norm before clipping. */
+typedef struct {
+  float* p;        /* parameter */
+  float* g;        /* its gradient (accumulator) */
+  float* m;        /* exp_avg */
+  float* v;        /* exp_avg_sq */
+  int32_t n;       /* elements of this chunk */
+  int32_t tensor;  /* number of the parameter tensor the chunk belongs to */
+} scm_adam_item;
+int scm_adam_chunk_elems(void);
+int scm_adam_step(const scm_adam_item* items /* device */, int n_chunks, float* ws, double grad_scale, double max_norm,
+                  double lr, double beta1, double beta2, double eps, int64_t step, float* norm_out, void* stream);
+
 /* ---- data ingest: SCDataset.__getitem__ (s1_pretrain_rna.py:133-137: data[index].toarray()[0], values above
  *      class_limit-2 set to it, .long()) and the scMomer rule (scmomer.py:56,108: round().long().clamp(0,5)) -----
  * The expression matrix is CSR in device memory (indptr int64 [n_rows+1], indices int32, values f32; duplicate

@@ -38,6 +38,11 @@ class WgradItem(C.Structure):
     _fields_ = [("Pm", vp), ("ldp", i64), ("Qm", vp), ("ldq", i64), ("P", i32), ("Q", i32), ("with_bias", i32), ("ws", vp)]
 
 
+class AdamItem(C.Structure):
+    """scm_adam_item"""
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i32), ("tensor", i32)]
+
+
 class FfnFwdArgs(C.Structure):
     """scm_ffn_fwd_args"""
     _fields_ = [("M", i64), ("D", i32), ("F", i32), ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp),
@@ -91,6 +96,8 @@ SIGNATURES = {
     "scm_s1_mask": (i32, [vp, vp, vp, i32, i32, C.c_float, C.c_float, i32, i64, i64, vp, vp, vp]),
     "scm_ce_ws_floats": (i64, [i64, i64]),
     "scm_ce_groups": (i64, [i64, i64]),
+    "scm_adam_chunk_elems": (i32, []),
+    "scm_adam_step": (i32, [vp, i32, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp, vp]),
     "scm_s1_accuracy_ws_ints": (i64, [i32, i32]),
     "scm_s1_accuracy": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp]),
     "scm_bin_max_genes": (i32, []),

@@ -49,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd", "gemm_res_ln"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd", "gemm_res_ln", "adam_step"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -532,6 +532,22 @@ int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, in
   SCM_REQ(logits && labels && ratio && counts && ws, "scm_s1_accuracy: null pointer");
   SCM_REQ(B > 0 && N > 0 && C >= 3 && C <= 64, "scm_s1_accuracy: need B, N > 0 and 3 <= C <= 64");
   SCM_HIP(s1_accuracy(logits, labels, B, N, C, pad_id, ratio, counts, ws, (hipStream_t)stream), "scm_s1_accuracy");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- optimizer step
+int scm_adam_chunk_elems(void) { return adam_chunk_elems(); }
+
+int scm_adam_step(const scm_adam_item* items, int n_chunks, float* ws, double grad_scale, double max_norm, double lr,
+                  double beta1, double beta2, double eps, int64_t step, float* norm_out, void* stream) {
+  SCM_REQ(items && ws && n_chunks > 0 && n_chunks <= (1 << 20), "scm_adam_step: null pointer or bad chunk count");
+  SCM_REQ(step >= 1 && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps > 0. && grad_scale > 0.,
+          "scm_adam_step: need step >= 1, 0 <= beta < 1, eps > 0, grad_scale > 0");
+  // the scalars as torch.optim.Adam forms them: Python doubles, rounded to f32 where they meet the tensors
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  AdamScalars k{(float)grad_scale, (float)max_norm, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                (float)(lr / bc1), (float)sqrt(bc2)};
+  SCM_HIP(adam_step(items, n_chunks, ws, k, norm_out, (hipStream_t)stream), "scm_adam_step");
   return 0;
 }
 

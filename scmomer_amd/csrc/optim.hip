@@ -1,0 +1,82 @@
+// The optimizer step of the S1 loop (s1_pretrain_rna.py:303-305: clip_grad_norm_(parameters, 100), Adam.step(),
+// zero_grad()) over ALL parameter tensors in two launches driven by one device table, instead of the hundred small
+// launches of the multi-tensor library calls.  The arithmetic is torch.optim.Adam's (betas, eps, no weight decay, no
+// amsgrad) operation by operation:
+//   g       = grad * grad_scale                      (grad_scale = 1 / world size: the average over the ranks)
+//   norm    = sqrt(sum over tensors of (sqrt(sum g^2))^2),  coef = min(1, max_norm / (norm + 1e-6)),  g *= coef
+//   m       = m + (g - m) * (1 - beta1)              (Tensor.lerp_)
+//   v       = v * beta2 + (1 - beta2) * g * g
+//   p       = p - (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+//   grad    = 0
+// The table lists chunks of at most ADAM_CHUNK elements, each inside one tensor; `tensor` numbers the tensor a chunk
+// belongs to (chunks of one tensor are consecutive), so the per-tensor norms can be formed as torch forms them.
+#include "scm_launch.hpp"
+
+namespace scm {
+
+constexpr int ADAM_CHUNK = 4096;
+
+// partial[c] = sum of (grad * grad_scale)^2 over chunk c
+__global__ __launch_bounds__(256) void adam_sqnorm_kernel(const AdamItem* __restrict__ items, float grad_scale,
+                                                          float* __restrict__ partial) {
+  __shared__ float ws[4];
+  const AdamItem it = items[blockIdx.x];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < it.n; i += 256) { const float g = it.g[i] * grad_scale; s += g * g; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// Every workgroup forms the total norm itself from the chunk partials (a few thousand floats out of the L2), in a
+// fixed order: chunk sums per tensor, square root per tensor, squares of those summed, square root.
+__global__ __launch_bounds__(256) void adam_update_kernel(const AdamItem* __restrict__ items, int nchunks,
+                                                          const float* __restrict__ partial, AdamScalars k,
+                                                          float* __restrict__ norm_out) {
+  __shared__ float ws[4];
+  __shared__ float coef_s;
+  // per-tensor sums: thread t walks the chunks t, t + 256, ...; a chunk adds to its tensor's slot only through the
+  // thread that owns the tensor's FIRST chunk, which then walks that tensor's consecutive chunks
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < nchunks; c += 256) {
+    if (c > 0 && items[c - 1].tensor == items[c].tensor) continue;   // not the first chunk of its tensor
+    float ts = 0.f;
+    for (int j = c; j < nchunks && items[j].tensor == items[c].tensor; ++j) ts += partial[j];
+    const float tn = sqrtf(ts);
+    acc += tn * tn;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf((ws[0] + ws[1]) + (ws[2] + ws[3]));
+    coef_s = k.max_norm > 0.f ? fminf(1.f, k.max_norm / (norm + 1e-6f)) : 1.f;
+    if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+  }
+  __syncthreads();
+  const float gs = k.grad_scale * coef_s;
+  const AdamItem it = items[blockIdx.x];
+  for (int i = threadIdx.x; i < it.n; i += 256) {
+    const float g = it.g[i] * gs;
+    float m = it.m[i], v = it.v[i];
+    m = m + (g - m) * k.one_minus_beta1;
+    v = v * k.beta2 + k.one_minus_beta2 * g * g;
+    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+    it.p[i] = it.p[i] - k.step_size * (m / denom);
+    it.m[i] = m;
+    it.v[i] = v;
+    it.g[i] = 0.f;
+  }
+}
+
+hipError_t adam_step(const AdamItem* items, int nchunks, float* partial, AdamScalars k, float* norm_out, hipStream_t s) {
+  Traced tr(K_ADAM, 0, s);
+  hipLaunchKernelGGL(adam_sqnorm_kernel, dim3(nchunks), dim3(256), 0, s, items, k.grad_scale, partial);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(nchunks), dim3(256), 0, s, items, nchunks, partial, k, norm_out);
+  return hipGetLastError();
+}
+
+int adam_chunk_elems() { return ADAM_CHUNK; }
+
+}  // namespace scm

@@ -70,6 +70,19 @@ class GradientAverager:
             off += p.numel()
 
     @torch.no_grad()
+    def sum_in_place_(self) -> None:
+        """The all-reduce alone, on the bucket in place (the caller accumulates into ``views`` and divides by the
+        world size itself, e.g. inside its optimizer kernel)."""
+        if self.world == 1:
+            return
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
     def average_(self) -> None:
         """p.grad <- mean over ranks of p.grad, for every parameter (a missing grad counts as zero).  A caller that
         accumulates straight into ``views`` (p.grad is the view itself) pays no gather/scatter copies: the

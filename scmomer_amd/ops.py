@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import FavorPlan, FfnFwdArgs, ReduceJob, View4, WgradItem, check, lib
+from ._lib import AdamItem, FavorPlan, FfnFwdArgs, ReduceJob, View4, WgradItem, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -540,6 +540,49 @@ def s1_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int):
     check(lib.scm_s1_accuracy(_p(logits), _p(labels), b, n, c, pad_id, _p(ratio), _p(counts), _p(ws), _stream()),
           "scm_s1_accuracy")
     return ratio, counts
+
+
+# ----------------------------------------------------------------------------- optimizer step
+class AdamTable:
+    """Device table of scm_adam_item chunks over (parameter, gradient, exp_avg, exp_avg_sq) quadruples: built once
+    per set of tensors, reused by every adam_step (the tensors' storage must stay where it is)."""
+
+    def __init__(self, params, grads, exp_avgs, exp_avg_sqs):
+        import ctypes
+        chunk = lib.scm_adam_chunk_elems()
+        items = []
+        self.keys = []
+        for ti, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+            for t, nm in ((p, "parameter"), (g, "gradient"), (m, "exp_avg"), (v, "exp_avg_sq")):
+                _req(t, F32, nm)
+                if t.numel() != p.numel():
+                    raise ValueError(f"{nm}: {t.numel()} elements for a parameter of {p.numel()}")
+            self.keys.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
+            for off in range(0, p.numel(), chunk):
+                it = AdamItem()
+                it.p, it.g, it.m, it.v = (t.data_ptr() + 4 * off for t in (p, g, m, v))
+                it.n, it.tensor = min(chunk, p.numel() - off), ti
+                items.append(it)
+        arr = (AdamItem * len(items))(*items)
+        raw = bytes(memoryview(arr).cast("B"))
+        dev = params[0].device
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.n_chunks = len(items)
+        self.ws = torch.empty(len(items), dtype=F32, device=dev)
+        self.norm = torch.zeros(1, dtype=F32, device=dev)
+
+    def matches(self, params, grads, exp_avgs, exp_avg_sqs) -> bool:
+        return self.keys == [(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+                             for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs)]
+
+
+def adam_step(table: AdamTable, *, step: int, lr: float, beta1: float, beta2: float, eps: float, max_norm: float,
+              grad_scale: float = 1.0) -> torch.Tensor:
+    """clip_grad_norm_(max_norm) + Adam.step() + zero_grad() over every tensor of the table in two launches; -> the
+    gradient norm before clipping (device scalar, overwritten by the next call)"""
+    check(lib.scm_adam_step(table.table.data_ptr(), table.n_chunks, _p(table.ws), grad_scale, max_norm, lr, beta1, beta2,
+                            eps, step, _p(table.norm), _stream()), "scm_adam_step")
+    return table.norm
 
 
 # ----------------------------------------------------------------------------- ingest, projection redraw

@@ -225,7 +225,8 @@ class S1Trainer:
     def __init__(self, model, *, learning_rate: float = 1e-4, grad_acc: int = 20, mask_prob: float = 0.15,
                  replace_prob: float = 0.9, bin_num: int = 5, max_grad_norm: float = int(1e2),
                  group: Optional[dist.ProcessGroup] = None, use_graph: bool = False,
-                 mask_fn: Optional[Callable] = None, loss_fn: Optional[Callable] = None, window: int = 1):
+                 mask_fn: Optional[Callable] = None, loss_fn: Optional[Callable] = None, window: int = 1,
+                 fused_optimizer: bool = True):
         self.model = model
         self.grad_acc = int(grad_acc)
         self.window = int(window)
@@ -260,6 +261,8 @@ class S1Trainer:
         self.use_graph = use_graph
         self._recorded: Dict[Tuple[tuple, int], _Recorded] = {}
         self._graph_auto = None                              # the model's own redraw switch while graphs exist
+        self.fused_optimizer = fused_optimizer               # clip + Adam + zero as one device kernel where possible
+        self._adam_table = None
 
     # ---- one micro-step, or a window of them -------------------------------------------------
     def _mask_window(self, data: torch.Tensor, groups: int):
@@ -326,8 +329,48 @@ class S1Trainer:
             return loss.detach(), s1_batch_accuracy(logits.detach(), labels, self.pad_id)
         return loss.detach(), s1_cell_accuracy(logits.detach(), labels, self.pad_id).view(groups, b).mean(dim=1)
 
+    def _fused_tail_state(self):
+        """(exp_avgs, exp_avg_sqs, steps) of torch.optim.Adam for the trainable parameters, or None when the step
+        cannot go through the two-launch optimizer kernel: parameters off the GPU or not f32, an Adam variant the
+        kernel does not implement, or moments that do not exist yet (torch creates them in its first step)."""
+        if not self.fused_optimizer or not self.params or not all(p.is_cuda and p.dtype == torch.float32 and
+                                                                  p.is_contiguous() for p in self.params):
+            return None
+        opt = self.optimizer
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return None
+        g = opt.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or \
+                g.get("differentiable") or isinstance(g["lr"], torch.Tensor):
+            return None
+        ms, vs, steps = [], [], []
+        for p in self.params:
+            st = opt.state.get(p)
+            if not st or "exp_avg" not in st or not st["exp_avg"].is_cuda:
+                return None
+            ms.append(st["exp_avg"]), vs.append(st["exp_avg_sq"]), steps.append(st["step"])
+        return ms, vs, steps
+
     def _optimizer_step(self):
-        """The sync micro-step's tail (s1_pretrain_rna.py:299-305): average over ranks, clip, Adam, zero."""
+        """The sync micro-step's tail (s1_pretrain_rna.py:299-305): average over ranks, clip, Adam, zero.  On the GPU
+        (from the second optimizer step on: torch creates Adam's moments in the first) this is one all-reduce, the
+        two launches of the optimizer kernel and the one-launch refresh of the bf16 weight copies; Adam's state stays
+        torch's own (same state_dict)."""
+        fused = self._fused_tail_state()
+        if fused is not None:
+            from . import ops, stack
+            ms, vs, steps = fused
+            if self._adam_table is None or not self._adam_table.matches(self.params, self.accs, ms, vs):
+                self._adam_table = ops.AdamTable(self.params, self.accs, ms, vs)
+            self.averager.sum_in_place_()
+            for st in steps:
+                st += 1
+            g = self.optimizer.param_groups[0]
+            ops.adam_step(self._adam_table, step=int(steps[0]), lr=float(g["lr"]), beta1=g["betas"][0], beta2=g["betas"][1],
+                          eps=g["eps"], max_norm=float(self.max_grad_norm), grad_scale=1.0 / self.world)
+            torch.autograd.graph.increment_version(self.params)      # the kernel wrote the parameters in place
+            stack.refresh_weights(self.model)
+            return
         for p, a in zip(self.params, self.accs):
             p.grad = a
         if self.averager is not None:

@@ -362,3 +362,74 @@ def test_fifty_optimizer_steps_track_the_fp32_oracle(mods):
                 worst_u = (k, cu)
             assert cu >= 0.9, f"{k}: update cosine {cu:.4f}"
     print(f"after 50 optimizer steps: worst weight cosine {worst_w}, worst update cosine {worst_u}")
+
+
+@pytest.mark.parametrize("max_norm,world", [(100.0, 1), (0.05, 1), (0.7, 4)])
+def test_optimizer_kernel_equals_torch_clip_and_adam(mods, max_norm, world):
+    """clip_grad_norm_ + Adam.step() + zero_grad() (s1_pretrain_rna.py:303-305) as the two-launch optimizer kernel
+    against the torch library calls it replaces, fed the SAME gradients for four steps (tensors of the model's
+    shapes, one of them longer than a chunk, one of 7 elements): parameters and both moments agree to f32 rounding
+    (a different association in two products), the norm equals clip_grad_norm_'s, the gradients are zeroed; with the
+    clip inactive and active, and with the 1/world average folded into the kernel."""
+    from scmomer_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(7, 200), (200,), (640, 200), (1920, 200), (800,), (7,), (200, 800)]
+    p_t = [torch.nn.Parameter(torch.randn(s_, generator=gen).to(DEV)) for s_ in shapes]
+    p_f = [p.detach().clone() for p in p_t]
+    opt = torch.optim.Adam(p_t, lr=3e-3)
+    flat = torch.zeros(sum(p.numel() for p in p_f), device=DEV)
+    views, off = [], 0
+    for p in p_f:
+        views.append(flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
+    ms = [torch.zeros_like(p) for p in p_f]
+    vs = [torch.zeros_like(p) for p in p_f]
+    table = ops.AdamTable(p_f, views, ms, vs)
+    assert table.n_chunks == sum((p.numel() + 4095) // 4096 for p in p_f)
+    for step in range(1, 5):
+        grads = [(torch.randn(s_, generator=gen) * (10.0 ** (step - 3))).to(DEV) for s_ in shapes]
+        for p, g, v in zip(p_t, grads, views):
+            p.grad = g / world                               # what the average over the ranks leaves
+            v.copy_(g)                                       # the kernel gets the sum and divides itself
+        want_norm = torch.nn.utils.clip_grad_norm_(p_t, max_norm)
+        opt.step()
+        got_norm = ops.adam_step(table, step=step, lr=3e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=max_norm,
+                                 grad_scale=1.0 / world)
+        torch.testing.assert_close(got_norm.reshape(()), want_norm, rtol=1e-5, atol=0)
+        assert float(flat.abs().max()) == 0.0
+        for a, b_, m, v, p in zip(p_f, p_t, ms, vs, p_t):
+            st = opt.state[p]
+            # elements where 0.9 m and 0.1 g nearly cancel carry the rounding of the larger terms: absolute part
+            torch.testing.assert_close(m, st["exp_avg"], rtol=1e-5, atol=1e-6 * float(st["exp_avg"].abs().max()))
+            torch.testing.assert_close(v, st["exp_avg_sq"], rtol=1e-5, atol=1e-20)
+            torch.testing.assert_close(a, b_.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_trainer_uses_the_optimizer_kernel_and_keeps_torchs_state(mods):
+    """S1Trainer takes its optimizer steps through the kernel from the second step on (torch's first step creates
+    the moments), keeps torch.optim.Adam's own state (step counters advance, same state_dict keys), zeroes the
+    accumulators and refreshes the bf16 weight copies (the next forward sees the new weights); against the same
+    run on the torch tail the first two optimizer steps' weights agree to rounding."""
+    ingest, s1, train = mods
+    n, b = 517, 3
+    tok = [torch.from_numpy(np.minimum(_cells(i, b, n), 5).astype(np.int64)).to(DEV) for i in range(4)]
+    runs = []
+    for fused in (False, True):
+        m = _model(n)
+        tr = train.S1Trainer(m, learning_rate=0.01, grad_acc=2, fused_optimizer=fused, use_graph=True)
+        tr.scheduler.step(), tr.scheduler.step()
+        torch.manual_seed(3)
+        losses = [float(tr.micro_step(t)[0]) for t in tok]
+        assert (tr._adam_table is not None) == fused
+        st = tr.optimizer.state_dict()["state"]
+        assert all(float(v["step"]) == 2.0 for v in st.values())
+        assert max(float(a.abs().max()) for a in tr.accs) == 0.0
+        runs.append((m.state_dict(), losses))
+    (sd_t, l_t), (sd_f, l_f) = runs
+    assert l_t == l_f                                        # the second window ran on the same (first-step) weights
+    fresh = _model(n).state_dict()
+    for k in sd_t:
+        if sd_t[k].dtype == torch.float32 and not k.endswith("projection_matrix"):
+            moved = float((sd_t[k] - fresh[k]).abs().max())
+            assert moved > 0
+            torch.testing.assert_close(sd_f[k], sd_t[k], rtol=0, atol=2e-5 * moved, msg=k)
