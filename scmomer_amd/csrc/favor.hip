@@ -110,6 +110,13 @@ SCM_DEV f32x16 score_tile(const char* omg, int t, const bf16x8 (&xf)[4]) {
   return x;
 }
 
+// The last feature tile holds NF - 32 (NFT - 1) = 10 real features: accumulator rows 0..9, i.e. register groups
+// g < LAST_GROUPS (rows 8g .. 8g+7) and k-steps sk < LAST_KSTEPS (rows 16 sk .. 16 sk + 15) of the products that
+// contract over features.  Everything beyond is padding, known at compile time: no exponentials, no products.
+constexpr int LAST_VALID = NF - 32 * (NFT - 1);
+constexpr int LAST_GROUPS = (LAST_VALID + 7) / 8;
+constexpr int LAST_KSTEPS = (LAST_VALID + 15) / 16;
+
 // feature index of accumulator element r in tile t; valid iff < 266
 SCM_DEV bool feat_valid(int t, int r, int half) { return t < NFT - 1 || acc_row(r, half) < NF - 32 * (NFT - 1); }
 
@@ -791,9 +798,11 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
       float dsum = 0.f;
 #pragma unroll
       for (int t = 0; t < NFT; ++t) {
-        f32x16 e;
+        f32x16 e = zero16();
+        const int ng = (t == NFT - 1) ? LAST_GROUPS : 4, nsk = (t == NFT - 1) ? LAST_KSTEPS : 2;   // compile-time (unrolled)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          if (g >= ng) continue;
           const f32x4 z4 = *(const f32x4*)(zv + 32 * t + 8 * g + 4 * half);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -806,6 +815,7 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
         }
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk) {
+          if (sk >= nsk) continue;
           const bf16x8 ef = acc_to_frag(e, sk);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
@@ -857,10 +867,10 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
           X = mfma32(*(const bf16x8*)(ob_ + lo.row[ks]), xf[ks], X);
           G = mfma32(*(const bf16x8*)(mb_ + lo.row[ks]), dof[ks], G);
         }
-        f32x16 dA;
+        f32x16 dA = zero16();
         int jr = 64;   // row (without the 4*half part) of the first arg-max element of this tile, if any
 #pragma unroll
-        for (int g = 3; g >= 0; --g) {
+        for (int g = (LAST ? LAST_GROUPS : 4) - 1; g >= 0; --g) {
           const f32x4 z4 = *(const f32x4*)(zv + 32 * t + 8 * g + 4 * half);
 #pragma unroll
           for (int i = 3; i >= 0; --i) {
@@ -879,7 +889,7 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
         }
         jstar = (jr < 64 && jstar >= (1 << 20)) ? 32 * t + jr + 4 * half : jstar;
 #pragma unroll
-        for (int sk = 0; sk < 2; ++sk) {
+        for (int sk = 0; sk < (LAST ? LAST_KSTEPS : 2); ++sk) {
           const bf16x8 af = acc_to_frag(dA, sk);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) Y[dt] = mfma32(tr_frag_at(ob_, lo.tr[sk][dt]), af, Y[dt]);
@@ -951,9 +961,9 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
           X = mfma32(*(const bf16x8*)(ob_ + lo.row[ks]), xf[ks], X);
           G = mfma32(*(const bf16x8*)(mb_ + lo.row[ks]), vf[ks], G);
         }
-        f32x16 E, dA;
+        f32x16 E = zero16(), dA = zero16();
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < (LAST ? LAST_GROUPS : 4); ++g) {
           const f32x4 z4 = *(const f32x4*)(zv + 32 * t + 8 * g + 4 * half);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -967,7 +977,7 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
           }
         }
 #pragma unroll
-        for (int sk = 0; sk < 2; ++sk) {
+        for (int sk = 0; sk < (LAST ? LAST_KSTEPS : 2); ++sk) {
           const bf16x8 af = acc_to_frag(dA, sk);
           const bf16x8 ef = acc_to_frag(E, sk);
 #pragma unroll
