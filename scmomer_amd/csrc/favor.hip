@@ -787,7 +787,9 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
       float mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < NFT; ++t) {
-        X[t] = score_tile(omg, t, xf);
+        X[t] = zero16();   // Omega_t (32x64) * q^T (64x32); block t of the image at +4096 t from the lane's offsets
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) X[t] = mfma32(*(const bf16x8*)(omg + 4096 * t + lo.row[ks]), xf[ks], X[t]);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (feat_valid(t, r, half)) mx = fmaxf(mx, X[t][r]);
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(MODE == 1 ? 768 : 512) void favor_apply_kernel(Appl
           const bf16x8 ef = acc_to_frag(e, sk);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            Y[dt] = mfma32(img_tr_frag<true>(mim, 32 * t + 16 * sk, 32 * dt), ef, Y[dt]);
+            Y[dt] = mfma32(tr_frag_at(mim + 4096 * t, lo.tr[sk][dt]), ef, Y[dt]);
         }
       }
       const float den = xhalf_sum(dsum) + KEPS * zsum;
