@@ -312,7 +312,7 @@ int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, in
                     int* counts, int* ws, void* stream);
 
 /* ---- the optimizer step of the S1 loop: s1_pretrain_rna.py:303-305 (clip_grad_norm_(model.parameters(), 100),
- *      optimizer.step() of the Adam built at :247, optimizer.zero_grad()) over every parameter tensor in TWO launches.
+ *      optimizer.step() of the Adam built at :247, optimizer.zero_grad()) over every parameter tensor in THREE launches.
  *      The table (DEVICE memory) lists chunks of at most scm_adam_chunk_elems() consecutive elements, each inside one
  *      parameter tensor; the chunks of a tensor are consecutive and carry the tensor's number.  Per element, with
  *      g = grad * grad_scale (grad_scale = 1 / world size after the gradient all-reduce):
@@ -322,7 +322,7 @@ int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, in
  *        param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps);  grad = 0
  *      i.e. torch.optim.Adam (no weight decay, no amsgrad) operation by operation; `step` is the step number AFTER
  *      the increment (>= 1); the hyper-parameters are doubles, as torch holds them (1 - beta is formed in double).
- *      ws: n_chunks floats.  norm_out (may be NULL): the total norm before clipping. */
+ *      ws: n_chunks + 2 floats.  norm_out (may be NULL): the total norm before clipping. */
 typedef struct {
   float* p;        /* parameter */
   float* g;        /* its gradient (accumulator) */

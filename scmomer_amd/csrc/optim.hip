@@ -1,5 +1,5 @@
 // The optimizer step of the S1 loop (s1_pretrain_rna.py:303-305: clip_grad_norm_(parameters, 100), Adam.step(),
-// zero_grad()) over ALL parameter tensors in two launches driven by one device table, instead of the hundred small
+// zero_grad()) over ALL parameter tensors in three launches driven by one device table, instead of the hundred small
 // launches of the multi-tensor library calls.  The arithmetic is torch.optim.Adam's (betas, eps, no weight decay, no
 // amsgrad) operation by operation:
 //   g       = grad * grad_scale                      (grad_scale = 1 / world size: the average over the ranks)
@@ -29,20 +29,20 @@ __global__ __launch_bounds__(256) void adam_sqnorm_kernel(const AdamItem* __rest
   if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-// Every workgroup forms the total norm itself from the chunk partials (a few thousand floats out of the L2), in a
-// fixed order: chunk sums per tensor, square root per tensor, squares of those summed, square root.
-__global__ __launch_bounds__(256) void adam_update_kernel(const AdamItem* __restrict__ items, int nchunks,
-                                                          const float* __restrict__ partial, AdamScalars k,
-                                                          float* __restrict__ norm_out) {
+// One workgroup forms the total norm from the chunk partials in a fixed order (chunk sums per tensor, square root per
+// tensor, squares of those summed, square root) and leaves the clip factor in scal[0] (the norm in scal[1]).
+__global__ __launch_bounds__(256) void adam_norm_kernel(const AdamItem* __restrict__ items, int nchunks,
+                                                        const float* __restrict__ partial, float max_norm,
+                                                        float* __restrict__ scal, float* __restrict__ norm_out) {
   __shared__ float ws[4];
-  __shared__ float coef_s;
-  // per-tensor sums: thread t walks the chunks t, t + 256, ...; a chunk adds to its tensor's slot only through the
-  // thread that owns the tensor's FIRST chunk, which then walks that tensor's consecutive chunks
+  // thread t walks the chunks t, t + 256, ...; the thread that meets a tensor's FIRST chunk sums that tensor's
+  // consecutive chunks
   float acc = 0.f;
   for (int c = threadIdx.x; c < nchunks; c += 256) {
-    if (c > 0 && items[c - 1].tensor == items[c].tensor) continue;   // not the first chunk of its tensor
+    const int tn_ = items[c].tensor;
+    if (c > 0 && items[c - 1].tensor == tn_) continue;   // not the first chunk of its tensor
     float ts = 0.f;
-    for (int j = c; j < nchunks && items[j].tensor == items[c].tensor; ++j) ts += partial[j];
+    for (int j = c; j < nchunks && items[j].tensor == tn_; ++j) ts += partial[j];
     const float tn = sqrtf(ts);
     acc += tn * tn;
   }
@@ -51,11 +51,15 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const AdamItem* __rest
   __syncthreads();
   if (threadIdx.x == 0) {
     const float norm = sqrtf((ws[0] + ws[1]) + (ws[2] + ws[3]));
-    coef_s = k.max_norm > 0.f ? fminf(1.f, k.max_norm / (norm + 1e-6f)) : 1.f;
-    if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+    scal[0] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    scal[1] = norm;
+    if (norm_out) *norm_out = norm;
   }
-  __syncthreads();
-  const float gs = k.grad_scale * coef_s;
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(const AdamItem* __restrict__ items,
+                                                          const float* __restrict__ scal, AdamScalars k) {
+  const float gs = k.grad_scale * scal[0];
   const AdamItem it = items[blockIdx.x];
   for (int i = threadIdx.x; i < it.n; i += 256) {
     const float g = it.g[i] * gs;
@@ -70,10 +74,13 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const AdamItem* __rest
   }
 }
 
+// partial: nchunks + 2 floats (chunk partials, then clip factor and norm)
 hipError_t adam_step(const AdamItem* items, int nchunks, float* partial, AdamScalars k, float* norm_out, hipStream_t s) {
   Traced tr(K_ADAM, 0, s);
   hipLaunchKernelGGL(adam_sqnorm_kernel, dim3(nchunks), dim3(256), 0, s, items, k.grad_scale, partial);
-  hipLaunchKernelGGL(adam_update_kernel, dim3(nchunks), dim3(256), 0, s, items, nchunks, partial, k, norm_out);
+  hipLaunchKernelGGL(adam_norm_kernel, dim3(1), dim3(256), 0, s, items, nchunks, partial, k.max_norm, partial + nchunks,
+                     norm_out);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(nchunks), dim3(256), 0, s, items, partial + nchunks, k);
   return hipGetLastError();
 }
 

@@ -568,7 +568,7 @@ class AdamTable:
         dev = params[0].device
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.n_chunks = len(items)
-        self.ws = torch.empty(len(items), dtype=F32, device=dev)
+        self.ws = torch.empty(len(items) + 2, dtype=F32, device=dev)
         self.norm = torch.zeros(1, dtype=F32, device=dev)
 
     def matches(self, params, grads, exp_avgs, exp_avg_sqs) -> bool:
@@ -578,7 +578,7 @@ class AdamTable:
 
 def adam_step(table: AdamTable, *, step: int, lr: float, beta1: float, beta2: float, eps: float, max_norm: float,
               grad_scale: float = 1.0) -> torch.Tensor:
-    """clip_grad_norm_(max_norm) + Adam.step() + zero_grad() over every tensor of the table in two launches; -> the
+    """clip_grad_norm_(max_norm) + Adam.step() + zero_grad() over every tensor of the table in three launches; -> the
     gradient norm before clipping (device scalar, overwritten by the next call)"""
     check(lib.scm_adam_step(table.table.data_ptr(), table.n_chunks, _p(table.ws), grad_scale, max_norm, lr, beta1, beta2,
                             eps, step, _p(table.norm), _stream()), "scm_adam_step")

@@ -331,7 +331,7 @@ class S1Trainer:
 
     def _fused_tail_state(self):
         """(exp_avgs, exp_avg_sqs, steps) of torch.optim.Adam for the trainable parameters, or None when the step
-        cannot go through the two-launch optimizer kernel: parameters off the GPU or not f32, an Adam variant the
+        cannot go through the optimizer kernel: parameters off the GPU or not f32, an Adam variant the
         kernel does not implement, or moments that do not exist yet (torch creates them in its first step)."""
         if not self.fused_optimizer or not self.params or not all(p.is_cuda and p.dtype == torch.float32 and
                                                                   p.is_contiguous() for p in self.params):
@@ -354,7 +354,7 @@ class S1Trainer:
     def _optimizer_step(self):
         """The sync micro-step's tail (s1_pretrain_rna.py:299-305): average over ranks, clip, Adam, zero.  On the GPU
         (from the second optimizer step on: torch creates Adam's moments in the first) this is one all-reduce, the
-        two launches of the optimizer kernel and the one-launch refresh of the bf16 weight copies; Adam's state stays
+        three launches of the optimizer kernel and the one-launch refresh of the bf16 weight copies; Adam's state stays
         torch's own (same state_dict)."""
         fused = self._fused_tail_state()
         if fused is not None:

@@ -366,7 +366,7 @@ def test_fifty_optimizer_steps_track_the_fp32_oracle(mods):
 
 @pytest.mark.parametrize("max_norm,world", [(100.0, 1), (0.05, 1), (0.7, 4)])
 def test_optimizer_kernel_equals_torch_clip_and_adam(mods, max_norm, world):
-    """clip_grad_norm_ + Adam.step() + zero_grad() (s1_pretrain_rna.py:303-305) as the two-launch optimizer kernel
+    """clip_grad_norm_ + Adam.step() + zero_grad() (s1_pretrain_rna.py:303-305) as the optimizer kernel
     against the torch library calls it replaces, fed the SAME gradients for four steps (tensors of the model's
     shapes, one of them longer than a chunk, one of 7 elements): parameters and both moments agree to f32 rounding
     (a different association in two products), the norm equals clip_grad_norm_'s, the gradients are zeroed; with the
