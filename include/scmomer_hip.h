@@ -311,6 +311,26 @@ int64_t scm_s1_accuracy_ws_ints(int B, int N);
 int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, int C, int64_t pad_id, float* ratio,
                     int* counts, int* ws, void* stream);
 
+/* ---- the tail of scMomer.get_cell_embedding after the encoder: scmomer.py:96-113 (rna_ln, encoder, to_out on the
+ *      concatenation) with _get_rna_features :124-130 (rna_projection, L2 normalisation) and the student encoder of
+ *      extract_cell_emb.py:27-40 (Linear, LayerNorm, GELU, Dropout (eval: off), Linear).  Forward only, f32, two
+ *      launches (one split-K kernel for the two G-wide products, one workgroup per cell for the narrow rest):
+ *        out = to_out(cat(W2 gelu(LN_h(W1 x + b1)) + b2,  LN_p(normalised(Wp genes))))
+ *      genes [B,G] f32 = the encoder's per-gene output (rna_encoder.py:11-16), x [B,G] f32 = the expression values.
+ *      All weights f32, row-major as nn.Linear holds them.  ws: scm_cell_tail_ws_floats(B, G, P, Hd) floats. */
+typedef struct {
+  int32_t P, Hd, O, normalize;       /* projection_dim, student hidden width, output width, config.normalize */
+  const float* Wp;                   /* rna_projection.weight [P, G] */
+  const float* ln_p_w; const float* ln_p_b;   /* rna_ln [P] */
+  const float* W1; const float* b1;  /* encoder.encoder.0 [Hd, G], [Hd] */
+  const float* ln_h_w; const float* ln_h_b;   /* encoder.encoder.1 [Hd] */
+  const float* W2; const float* b2;  /* encoder.encoder.4 [P, Hd], [P] */
+  const float* Wo; const float* bo;  /* to_out [O, 2 P], [O] */
+} scm_cell_tail_args;
+int64_t scm_cell_tail_ws_floats(int B, int G, int P, int Hd);
+int scm_cell_tail_fwd(const float* genes, const float* x, int B, int G, const scm_cell_tail_args* a /* host */,
+                      float* ws, float* out, void* stream);
+
 /* ---- the optimizer step of the S1 loop: s1_pretrain_rna.py:303-305 (clip_grad_norm_(model.parameters(), 100),
  *      optimizer.step() of the Adam built at :247, optimizer.zero_grad()) over every parameter tensor in THREE launches.
  *      The table (DEVICE memory) lists chunks of at most scm_adam_chunk_elems() consecutive elements, each inside one

@@ -43,6 +43,12 @@ class AdamItem(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i32), ("tensor", i32)]
 
 
+class CellTailArgs(C.Structure):
+    """scm_cell_tail_args"""
+    _fields_ = [("P", i32), ("Hd", i32), ("O", i32), ("normalize", i32), ("Wp", vp), ("ln_p_w", vp), ("ln_p_b", vp),
+                ("W1", vp), ("b1", vp), ("ln_h_w", vp), ("ln_h_b", vp), ("W2", vp), ("b2", vp), ("Wo", vp), ("bo", vp)]
+
+
 class FfnFwdArgs(C.Structure):
     """scm_ffn_fwd_args"""
     _fields_ = [("M", i64), ("D", i32), ("F", i32), ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp),
@@ -96,6 +102,8 @@ SIGNATURES = {
     "scm_s1_mask": (i32, [vp, vp, vp, i32, i32, C.c_float, C.c_float, i32, i64, i64, vp, vp, vp]),
     "scm_ce_ws_floats": (i64, [i64, i64]),
     "scm_ce_groups": (i64, [i64, i64]),
+    "scm_cell_tail_ws_floats": (i64, [i32, i32, i32, i32]),
+    "scm_cell_tail_fwd": (i32, [vp, vp, i32, i32, C.POINTER(CellTailArgs), vp, vp, vp]),
     "scm_adam_chunk_elems": (i32, []),
     "scm_adam_step": (i32, [vp, i32, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp, vp]),
     "scm_s1_accuracy_ws_ints": (i64, [i32, i32]),

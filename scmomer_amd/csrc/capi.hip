@@ -49,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd", "gemm_res_ln", "adam_step"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd", "gemm_res_ln", "adam_step", "cell_tail"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -532,6 +532,25 @@ int scm_s1_accuracy(const float* logits, const int64_t* labels, int B, int N, in
   SCM_REQ(logits && labels && ratio && counts && ws, "scm_s1_accuracy: null pointer");
   SCM_REQ(B > 0 && N > 0 && C >= 3 && C <= 64, "scm_s1_accuracy: need B, N > 0 and 3 <= C <= 64");
   SCM_HIP(s1_accuracy(logits, labels, B, N, C, pad_id, ratio, counts, ws, (hipStream_t)stream), "scm_s1_accuracy");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- cell-embedding tail
+static bool cell_tail_sizes_ok(int B, int G, int P, int Hd, int O) {
+  return B > 0 && G > 0 && P > 0 && Hd > 0 && O > 0 && P + Hd <= 1024 && P <= 1024 && Hd <= 1024 && O <= 1024 &&
+         (P + Hd) % 64 == 0;
+}
+int64_t scm_cell_tail_ws_floats(int B, int G, int P, int Hd) {
+  return cell_tail_sizes_ok(B, G, P, Hd, 1) ? (int64_t)cell_tail_ws_floats(B, G, P, Hd) : 0;
+}
+int scm_cell_tail_fwd(const float* genes, const float* x, int B, int G, const scm_cell_tail_args* a, float* ws,
+                      float* out, void* stream) {
+  SCM_REQ(genes && x && a && ws && out, "scm_cell_tail_fwd: null pointer");
+  SCM_REQ(cell_tail_sizes_ok(B, G, a->P, a->Hd, a->O),
+          "scm_cell_tail_fwd: need P, Hd, O <= 1024, P + Hd <= 1024 and a multiple of 64 (P=%d Hd=%d O=%d)", a->P, a->Hd, a->O);
+  SCM_REQ(a->Wp && a->ln_p_w && a->ln_p_b && a->W1 && a->b1 && a->ln_h_w && a->ln_h_b && a->W2 && a->b2 && a->Wo && a->bo,
+          "scm_cell_tail_fwd: null weight pointer");
+  SCM_HIP(cell_tail(genes, x, B, G, *a, ws, out, (hipStream_t)stream), "scm_cell_tail_fwd");
   return 0;
 }
 

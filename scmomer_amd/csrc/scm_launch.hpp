@@ -88,7 +88,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
   K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_BIN, K_OMEGA_QR, K_FEATURE_MAP, K_LINEAR_ATTENTION, K_FFN_CHAIN_FWD,
-  K_REDUCE_BATCH, K_GEMM_LN_BWD, K_GEMM_RES_LN, K_ADAM, K_COUNT
+  K_REDUCE_BATCH, K_GEMM_LN_BWD, K_GEMM_RES_LN, K_ADAM, K_CELL_TAIL, K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
@@ -176,6 +176,12 @@ using AdamItem = ::scm_adam_item;
 struct AdamScalars { float grad_scale, max_norm, one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bc2_sqrt; };
 int adam_chunk_elems();
 hipError_t adam_step(const AdamItem* items, int nchunks, float* partial, AdamScalars k, float* norm_out, hipStream_t s);
+
+// cell_tail.hip
+using CellTailArgs = ::scm_cell_tail_args;
+long cell_tail_ws_floats(int B, int G, int P, int Hd);
+hipError_t cell_tail(const float* genes, const float* x, int B, int G, CellTailArgs a, float* ws, float* out,
+                     hipStream_t s);
 
 // s1_tail.hip
 hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,

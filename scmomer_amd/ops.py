@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import AdamItem, FavorPlan, FfnFwdArgs, ReduceJob, View4, WgradItem, check, lib
+from ._lib import AdamItem, CellTailArgs, FavorPlan, FfnFwdArgs, ReduceJob, View4, WgradItem, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -540,6 +540,31 @@ def s1_accuracy(logits: torch.Tensor, labels: torch.Tensor, pad_id: int):
     check(lib.scm_s1_accuracy(_p(logits), _p(labels), b, n, c, pad_id, _p(ratio), _p(counts), _p(ws), _stream()),
           "scm_s1_accuracy")
     return ratio, counts
+
+
+# ----------------------------------------------------------------------------- cell-embedding tail
+def cell_tail_supported(p: int, hd: int, o: int) -> bool:
+    return p <= 1024 and hd <= 1024 and o <= 1024 and p + hd <= 1024 and (p + hd) % 64 == 0
+
+
+def cell_tail(genes, x, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo, normalize: bool) -> torch.Tensor:
+    """scMomer.get_cell_embedding after the encoder (forward only, f32): genes, x [B,G]; wp [P,G]; ln_p = (w, b) of
+    rna_ln; w1 [Hd,G], b1; ln_h = (w, b); w2 [P,Hd], b2; wo [O,2P], bo  ->  [B,O]"""
+    tensors = (genes, x, wp, *ln_p, w1, b1, *ln_h, w2, b2, wo, bo)
+    for t in tensors:
+        _req(t, F32, "cell_tail operand")
+    b, g = genes.shape
+    p, hd, o = wp.shape[0], w1.shape[0], wo.shape[0]
+    if x.shape != genes.shape or wp.shape[1] != g or w1.shape[1] != g or tuple(w2.shape) != (p, hd) or wo.shape[1] != 2 * p:
+        raise ValueError("cell_tail: inconsistent shapes")
+    a = CellTailArgs()
+    a.P, a.Hd, a.O, a.normalize = p, hd, o, int(bool(normalize))
+    a.Wp, a.ln_p_w, a.ln_p_b, a.W1, a.b1 = _p(wp), _p(ln_p[0]), _p(ln_p[1]), _p(w1), _p(b1)
+    a.ln_h_w, a.ln_h_b, a.W2, a.b2, a.Wo, a.bo = _p(ln_h[0]), _p(ln_h[1]), _p(w2), _p(b2), _p(wo), _p(bo)
+    ws = torch.empty(lib.scm_cell_tail_ws_floats(b, g, p, hd), dtype=F32, device=genes.device)
+    out = torch.empty((b, o), dtype=F32, device=genes.device)
+    check(lib.scm_cell_tail_fwd(_p(genes), _p(x), b, g, C.byref(a), _p(ws), _p(out), _stream()), "scm_cell_tail_fwd")
+    return out
 
 
 # ----------------------------------------------------------------------------- optimizer step

@@ -168,3 +168,40 @@ def test_s3_step_graph_replay_equals_eager(S):
     assert c0 == c1 == len(batches)
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k
+
+
+@pytest.mark.parametrize("cells,genes,normalize", [(5, 16906, True), (40, 1000, False), (1, 33, True)])
+def test_cell_embedding_tail_kernel_equals_the_torch_tail(cells, genes, normalize):
+    """Everything of scMomer.get_cell_embedding after the encoder (scmomer.py:96-113,124-130; student encoder of
+    extract_cell_emb.py:27-40) as the two-launch f32 tail kernel against the same layers run by torch in f32: the
+    per-gene encoder output and the expression values are random, so only the tail is compared (sums of 16,906 f32
+    terms in another order: relative 1e-5 of the row scale)."""
+    import types
+    import scmomer_amd as S
+    from scmomer_amd import ops
+    torch.manual_seed(cells)
+    m = S.scMomer(types.SimpleNamespace(projection_dim=128, normalize=normalize), atac_config=None,
+                  encoder=S.StudentEncoder(genes, 128))
+    m.rna_projection = torch.nn.Linear(genes, 128, bias=False)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        for p in (m.rna_ln.weight, m.rna_ln.bias, m.encoder.encoder[1].weight, m.encoder.encoder[1].bias):
+            p.add_(0.3 * torch.randn_like(p))
+    gene_scores = torch.relu(torch.randn((cells, genes), device=DEV))
+    x = (torch.rand((cells, genes), device=DEV) < 0.2) * torch.rand((cells, genes), device=DEV) * 6
+    with torch.no_grad():
+        tail = m._tail_operands(x)
+        assert tail is not None
+        got = ops.cell_tail(gene_scores, x, *tail, normalize=normalize)
+        f = m.rna_projection(gene_scores)
+        if normalize:
+            f = f / f.norm(dim=-1, keepdim=True)
+        want = m.to_out(torch.cat([m.encoder(x), m.rna_ln(f)], 1))
+    assert tuple(got.shape) == (cells, 128)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale, float((got - want).abs().max()) / scale
+    m.train()
+    assert m._tail_operands(x) is None                      # dropout is active in train mode: torch's tail
+    m.eval()
+    with torch.enable_grad():
+        assert m._tail_operands(x) is None                  # gradients wanted: torch's tail
