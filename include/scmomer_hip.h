@@ -331,6 +331,50 @@ int64_t scm_cell_tail_ws_floats(int B, int G, int P, int Hd);
 int scm_cell_tail_fwd(const float* genes, const float* x, int B, int G, const scm_cell_tail_args* a /* host */,
                       float* ws, float* out, void* stream);
 
+/* ---- the trainable tail of the S3 distillation step: s3_pretrain_missing.py:291-307 (BCEWithLogitsLoss with
+ *      pos_weight on the binarised ATAC target :262,292-294, MSE on the RNA reconstruction, distill_weight * MSE
+ *      between the student's embedding and the teacher's, backward :299) over scMomer.forward(mode='one',
+ *      reconstruct=True) (scmomer.py:41-94) with the student encoder of extract_cell_emb.py:27-40 and the linear
+ *      decoders of utils.py:168-179.  The Performer, rna_projection and rna_ln are frozen (:233-246): `genes` is the
+ *      encoder's per-gene output and gets no gradient.  f32 throughout.
+ *      scm_distill_fwd: four launches -> losses[0..3] = {BCE, RNA MSE, distillation MSE, BCE + RNA MSE + distill_weight
+ *        * distillation MSE} (means, as torch forms them; the last is the sum the script backpropagates, :295), and
+ *        the tape the backward reads: the student's normalised hidden row, its dropped GELU output,
+ *        cat(student embedding, LayerNorm(normalised projection)), to_out's output, the LayerNorm's 1/std.
+ *      scm_distill_bwd: four launches -> the gradients of gloss[0] BCE + gloss[1] MSE_rna + gloss[2] MSE_distill
+ *        (gloss: three DEVICE floats) for the twelve trainable tensors, written (accumulate = 0) or added
+ *        (accumulate != 0: gradient accumulation, s3_pretrain_missing.py:296-299) to the given buffers.
+ *      drop: the dropout layer's multipliers (0 or 1 / (1 - p)) per hidden unit [B, Hd], drawn by the caller; NULL =
+ *        dropout off.  pos_weight: DEVICE, 1 value or one per peak.  B <= scm_distill_max_cells(); O must be 128.
+ *      tape: scm_distill_tape_floats(B, P, Hd, O) floats; ws: scm_distill_ws_floats(B, G, P, Hd, O, Na) floats, the
+ *      same buffer in the forward and its backward. */
+typedef struct {
+  scm_cell_tail_args tail;           /* the weights up to to_out, and config.normalize */
+  int32_t B, G, Na;                  /* cells, genes (= RNA decoder rows), ATAC peaks (= ATAC decoder rows) */
+  int32_t pos_weight_n;              /* 1 or Na */
+  float distill_weight;              /* weight of the distillation term in losses[3] */
+  int32_t reserved;
+  const float* Wa; const float* ba;  /* ATAC.output_mean.0 [Na, O], [Na] */
+  const float* Wr; const float* br;  /* RNA.output_mean.0 [G, O], [G] */
+  const float* genes;                /* [B, G] the encoder's per-gene output */
+  const float* x;                    /* [B, G] expression values: student input and RNA target */
+  const float* atac_raw;             /* [B, Na]; the target is atac_raw > 0 */
+  const float* latent;               /* [B, P] teacher embedding */
+  const float* drop;                 /* [B, Hd] or NULL */
+  const float* pos_weight;           /* device */
+} scm_distill_args;
+typedef struct {
+  float* dW1; float* db1; float* dln_w; float* dln_b; float* dW2; float* db2;   /* student encoder */
+  float* dWo; float* dbo;                                                       /* to_out */
+  float* dWa; float* dba; float* dWr; float* dbr;                               /* decoders */
+} scm_distill_grads;
+int scm_distill_max_cells(void);
+int64_t scm_distill_tape_floats(int B, int P, int Hd, int O);
+int64_t scm_distill_ws_floats(int B, int G, int P, int Hd, int O, int Na);
+int scm_distill_fwd(const scm_distill_args* a /* host */, float* tape, float* ws, float* losses, void* stream);
+int scm_distill_bwd(const scm_distill_args* a /* host */, const float* tape, float* ws, const float* gloss,
+                    const scm_distill_grads* g /* host */, int accumulate, void* stream);
+
 /* ---- the optimizer step of the S1 loop: s1_pretrain_rna.py:303-305 (clip_grad_norm_(model.parameters(), 100),
  *      optimizer.step() of the Adam built at :247, optimizer.zero_grad()) over every parameter tensor in THREE launches.
  *      The table (DEVICE memory) lists chunks of at most scm_adam_chunk_elems() consecutive elements, each inside one

@@ -49,6 +49,19 @@ class CellTailArgs(C.Structure):
                 ("W1", vp), ("b1", vp), ("ln_h_w", vp), ("ln_h_b", vp), ("W2", vp), ("b2", vp), ("Wo", vp), ("bo", vp)]
 
 
+class DistillArgs(C.Structure):
+    """scm_distill_args"""
+    _fields_ = [("tail", CellTailArgs), ("B", i32), ("G", i32), ("Na", i32), ("pos_weight_n", i32), ("distill_weight", C.c_float),
+                ("reserved", i32), ("Wa", vp), ("ba", vp),
+                ("Wr", vp), ("br", vp), ("genes", vp), ("x", vp), ("atac_raw", vp), ("latent", vp), ("drop", vp),
+                ("pos_weight", vp)]
+
+
+class DistillGrads(C.Structure):
+    """scm_distill_grads"""
+    _fields_ = [(n, vp) for n in ("dW1", "db1", "dln_w", "dln_b", "dW2", "db2", "dWo", "dbo", "dWa", "dba", "dWr", "dbr")]
+
+
 class FfnFwdArgs(C.Structure):
     """scm_ffn_fwd_args"""
     _fields_ = [("M", i64), ("D", i32), ("F", i32), ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp),
@@ -104,6 +117,11 @@ SIGNATURES = {
     "scm_ce_groups": (i64, [i64, i64]),
     "scm_cell_tail_ws_floats": (i64, [i32, i32, i32, i32]),
     "scm_cell_tail_fwd": (i32, [vp, vp, i32, i32, C.POINTER(CellTailArgs), vp, vp, vp]),
+    "scm_distill_max_cells": (i32, []),
+    "scm_distill_tape_floats": (i64, [i32, i32, i32, i32]),
+    "scm_distill_ws_floats": (i64, [i32, i32, i32, i32, i32, i32]),
+    "scm_distill_fwd": (i32, [C.POINTER(DistillArgs), vp, vp, vp, vp]),
+    "scm_distill_bwd": (i32, [C.POINTER(DistillArgs), vp, vp, vp, C.POINTER(DistillGrads), i32, vp]),
     "scm_adam_chunk_elems": (i32, []),
     "scm_adam_step": (i32, [vp, i32, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp, vp]),
     "scm_s1_accuracy_ws_ints": (i64, [i32, i32]),

@@ -49,7 +49,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "gemm_skinny/bf16", "gemm_skinny/f32_bias_res", "gemm_skinny/gelu_dual", "gemm_skinny/dgelu", "gemm_skinny/f32",
     "gemm_skinny/bf16_bias", "wgrad", "wgrad/bias", "wgrad_reduce", "cast_weight", "embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "head_fwd",
     "head_bwd", "colsum_reduce", "prep_omega", "favor_ctx_fwd", "favor_ctx_bwd", "favor_ctx_finalize",
-    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd", "gemm_res_ln", "adam_step", "cell_tail"};
+    "favor_apply_fwd", "favor_apply_bwd_q", "favor_apply_bwd_k", "favor_kfix", "s1_mask", "cross_entropy", "bin_cells", "omega_qr", "feature_map", "linear_attention", "ffn_chain_fwd", "reduce_batch", "gemm_ln_bwd", "gemm_res_ln", "adam_step", "cell_tail", "distill_tail"};
 struct TraceRec { int kid; double flops, bytes; hipEvent_t t0, t1; };
 static int g_trace_kid = -1;  // -1 off, K_COUNT = every kernel, else one kernel id
 static std::vector<TraceRec> g_trace;
@@ -551,6 +551,47 @@ int scm_cell_tail_fwd(const float* genes, const float* x, int B, int G, const sc
   SCM_REQ(a->Wp && a->ln_p_w && a->ln_p_b && a->W1 && a->b1 && a->ln_h_w && a->ln_h_b && a->W2 && a->b2 && a->Wo && a->bo,
           "scm_cell_tail_fwd: null weight pointer");
   SCM_HIP(cell_tail(genes, x, B, G, *a, ws, out, (hipStream_t)stream), "scm_cell_tail_fwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- distillation tail
+static const char* distill_args_problem(const scm_distill_args* a) {
+  if (!a) return "null argument block";
+  const scm_cell_tail_args& w = a->tail;
+  if (!cell_tail_sizes_ok(a->B, a->G, w.P, w.Hd, w.O)) return "need P, Hd, O <= 1024, P + Hd <= 1024 and a multiple of 64";
+  if (w.O != 128) return "the decoders' input width (to_out's output) must be 128";
+  if (a->B > distill_max_cells()) return "at most 32 cells per call";
+  if (a->Na <= 0) return "need at least one ATAC peak";
+  if ((int64_t)a->B * a->G >= (1ll << 31) || (int64_t)a->B * a->Na >= (1ll << 31)) return "operand too large";
+  if (!(w.Wp && w.ln_p_w && w.ln_p_b && w.W1 && w.b1 && w.ln_h_w && w.ln_h_b && w.W2 && w.b2 && w.Wo && w.bo && a->Wa &&
+        a->ba && a->Wr && a->br))
+    return "null weight pointer";
+  if (!(a->genes && a->x && a->atac_raw && a->latent && a->pos_weight)) return "null input pointer";
+  if (a->pos_weight_n != 1 && a->pos_weight_n != a->Na) return "pos_weight holds 1 or Na values";
+  return nullptr;
+}
+int scm_distill_max_cells(void) { return distill_max_cells(); }
+int64_t scm_distill_tape_floats(int B, int P, int Hd, int O) {
+  return (B > 0 && P > 0 && Hd > 0 && O > 0) ? (int64_t)distill_tape_floats(B, P, Hd, O) : 0;
+}
+int64_t scm_distill_ws_floats(int B, int G, int P, int Hd, int O, int Na) {
+  return (cell_tail_sizes_ok(B, G, P, Hd, O) && Na > 0) ? (int64_t)distill_ws_floats(B, G, P, Hd, O, Na) : 0;
+}
+int scm_distill_fwd(const scm_distill_args* a, float* tape, float* ws, float* losses, void* stream) {
+  const char* why = distill_args_problem(a);
+  SCM_REQ(!why, "scm_distill_fwd: %s", why);
+  SCM_REQ(tape && ws && losses, "scm_distill_fwd: null pointer");
+  SCM_HIP(distill_fwd(*a, tape, ws, losses, (hipStream_t)stream), "scm_distill_fwd");
+  return 0;
+}
+int scm_distill_bwd(const scm_distill_args* a, const float* tape, float* ws, const float* gloss,
+                    const scm_distill_grads* g, int accumulate, void* stream) {
+  const char* why = distill_args_problem(a);
+  SCM_REQ(!why, "scm_distill_bwd: %s", why);
+  SCM_REQ(tape && ws && gloss && g, "scm_distill_bwd: null pointer");
+  SCM_REQ(g->dW1 && g->db1 && g->dln_w && g->dln_b && g->dW2 && g->db2 && g->dWo && g->dbo && g->dWa && g->dba &&
+          g->dWr && g->dbr, "scm_distill_bwd: null gradient pointer");
+  SCM_HIP(distill_bwd(*a, tape, ws, gloss, *g, accumulate, (hipStream_t)stream), "scm_distill_bwd");
   return 0;
 }
 

@@ -17,45 +17,74 @@ namespace scm {
 SCM_DEV float gelu_erf_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }   // nn.GELU()
 
 constexpr int CT_KS = 32;            // gene columns per staged slice
-constexpr int CT_BG = 32;            // cells per workgroup (accumulators per thread)
+constexpr int CT_BG = 32;            // most cells per workgroup (accumulators per thread)
 constexpr int CT_PITCH = CT_KS + 1;  // LDS row pitch in floats: threads of consecutive rows hit distinct banks
+constexpr int CT_IV = 8;             // cell values a thread fetches per batch
 
-// grid (gene chunks, cell groups); block = P + Hd threads (one output column each, <= 1024).
+// grid (gene chunks, cell groups of BG); block = P + Hd threads (one output column each, <= 1024).
 // partial[chunk][b][col] = sum over the chunk's genes of in[b][g] * W[col][g], in = genes for col < P, x for the rest
-__global__ __launch_bounds__(1024) void cell_tail_products_kernel(const float* __restrict__ genes,
+// MAXT: the block size the register budget is sized for (512: 256 registers per thread, room for a whole slice's
+// loads in flight; 1024: 128)
+template <int BG, int MAXT>
+__global__ __launch_bounds__(MAXT) void cell_tail_products_kernel(const float* __restrict__ genes,
                                                                   const float* __restrict__ x, int B, int G,
                                                                   const float* __restrict__ Wp, int P,
                                                                   const float* __restrict__ W1, int Hd, int chunk_len,
                                                                   float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wl = (float*)smem;                              // [P + Hd][CT_PITCH]
-  float* il = wl + (P + Hd) * CT_PITCH;                  // [2][CT_BG][CT_KS]: genes rows, then x rows
+  float* il = wl + (P + Hd) * CT_PITCH;                  // [2][BG][CT_KS]: genes rows, then x rows
   const int tid = threadIdx.x, cols = P + Hd;
   const int g_lo = blockIdx.x * chunk_len, g_hi = min(G, g_lo + chunk_len);
-  const int b0 = blockIdx.y * CT_BG, nb = min(CT_BG, B - b0);
+  const int b0 = blockIdx.y * BG, nb = min(BG, B - b0);
   const bool is_p = tid < P;
-  float acc[CT_BG];
+  constexpr int IN_TOTAL = 2 * BG * CT_KS;
+  float acc[BG];
 #pragma unroll
-  for (int b = 0; b < CT_BG; ++b) acc[b] = 0.f;
+  for (int b = 0; b < BG; ++b) acc[b] = 0.f;
   for (int g0 = g_lo; g0 < g_hi; g0 += CT_KS) {
-    // stage: weight slice (cols x 32, each row's 128 bytes contiguous in memory) and the cells' slices
-    for (int i = tid; i < cols * CT_KS; i += blockDim.x) {
-      const int r = i / CT_KS, c = i % CT_KS, g = g0 + c;
-      const float* src = r < P ? Wp + (long)r * G : W1 + (long)(r - P) * G;
-      wl[r * CT_PITCH + c] = g < g_hi ? src[g] : 0.f;
-    }
-    for (int i = tid; i < 2 * CT_BG * CT_KS; i += blockDim.x) {
-      const int which = i / (CT_BG * CT_KS), j = i % (CT_BG * CT_KS), b = j / CT_KS, c = j % CT_KS, g = g0 + c;
-      const float* src = which == 0 ? genes : x;
-      il[i] = (b < nb && g < g_hi) ? src[(long)(b0 + b) * G + g] : 0.f;
+    // stage: weight slice (cols x 32, each row's 128 bytes contiguous in memory) and the cells' slices; the loads
+    // of a thread are issued together, before the first LDS write waits for one (blockDim.x == cols: exactly CT_KS
+    // weights per thread)
+    {
+      float wv[CT_KS];
+#pragma unroll
+      for (int k = 0; k < CT_KS; ++k) {
+        const int i = tid + k * cols, r = i / CT_KS, c = i % CT_KS, g = g0 + c;
+        const float* src = r < P ? Wp + (long)r * G : W1 + (long)(r - P) * G;
+        wv[k] = g < g_hi ? src[g] : 0.f;
+      }
+      for (int base = 0; base < IN_TOTAL; base += CT_IV * cols) {
+        float iv[CT_IV];
+#pragma unroll
+        for (int k = 0; k < CT_IV; ++k) {
+          const int i = base + tid + k * cols;
+          iv[k] = 0.f;
+          if (i < IN_TOTAL) {
+            const int which = i / (BG * CT_KS), j = i % (BG * CT_KS), b = j / CT_KS, c = j % CT_KS, g = g0 + c;
+            const float* src = which == 0 ? genes : x;
+            if (b < nb && g < g_hi) iv[k] = src[(long)(b0 + b) * G + g];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < CT_IV; ++k) {
+          const int i = base + tid + k * cols;
+          if (i < IN_TOTAL) il[i] = iv[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < CT_KS; ++k) {
+        const int i = tid + k * cols;
+        wl[(i / CT_KS) * CT_PITCH + i % CT_KS] = wv[k];
+      }
     }
     __syncthreads();
     float wr[CT_KS];
 #pragma unroll
     for (int c = 0; c < CT_KS; ++c) wr[c] = wl[tid * CT_PITCH + c];
-    const float* in = il + (is_p ? 0 : CT_BG * CT_KS);
+    const float* in = il + (is_p ? 0 : BG * CT_KS);
 #pragma unroll
-    for (int b = 0; b < CT_BG; ++b) {
+    for (int b = 0; b < BG; ++b) {
       float s = acc[b];
 #pragma unroll
       for (int c = 0; c < CT_KS; ++c) s = fmaf(in[b * CT_KS + c], wr[c], s);   // broadcast reads
@@ -65,7 +94,7 @@ __global__ __launch_bounds__(1024) void cell_tail_products_kernel(const float* _
   }
   float* out = partial + ((long)blockIdx.x * B + b0) * cols + tid;
 #pragma unroll
-  for (int b = 0; b < CT_BG; ++b)
+  for (int b = 0; b < BG; ++b)
     if (b < nb) out[(long)b * cols] = acc[b];
 }
 
@@ -89,8 +118,10 @@ __global__ __launch_bounds__(1024) void cell_tail_finish_kernel(const float* __r
   const int tid = threadIdx.x, b = blockIdx.x, cols = a.P + a.Hd, nw = blockDim.x >> 6;
   // encoder branch: projection -> L2 normalisation -> LayerNorm
   float f = 0.f;
-  if (tid < a.P)
+  if (tid < a.P) {
+#pragma unroll 8
     for (int c = 0; c < nchunks; ++c) f += partial[((long)c * B + b) * cols + tid];
+  }
   if (a.normalize) {
     const float n2 = block_sum(tid < a.P ? f * f : 0.f, red, nw);
     f = f / sqrtf(n2);
@@ -104,6 +135,7 @@ __global__ __launch_bounds__(1024) void cell_tail_finish_kernel(const float* __r
   // student branch: first Linear (partials + bias) -> LayerNorm -> GELU
   float h = 0.f;
   if (tid < a.Hd) {
+#pragma unroll 8
     for (int c = 0; c < nchunks; ++c) h += partial[((long)c * B + b) * cols + a.P + tid];
     h += a.b1[tid];
   }
@@ -137,17 +169,43 @@ int cell_tail_chunks(int G) {
 }
 long cell_tail_ws_floats(int B, int G, int P, int Hd) { return (long)cell_tail_chunks(G) * B * (P + Hd); }
 
-hipError_t cell_tail(const float* genes, const float* x, int B, int G, CellTailArgs a, float* ws, float* out,
-                     hipStream_t s) {
+// the split-K products alone: ws[chunk][b][P + Hd]; *nchunks = the number of gene chunks the caller sums over
+template <int BG, int MAXT>
+static hipError_t launch_products(const float* genes, const float* x, int B, int G, const CellTailArgs& a, float* ws,
+                                  int nch, int chunk_len, hipStream_t s) {
+  const int cols = a.P + a.Hd;
+  const size_t lds = ((size_t)cols * CT_PITCH + 2 * BG * CT_KS) * sizeof(float);
+  static std::atomic<unsigned long long> ready;
+  if (hipError_t e = ensure_dynamic_lds((const void*)(cell_tail_products_kernel<BG, MAXT>), lds, ready); e != hipSuccess) return e;
+  hipLaunchKernelGGL((cell_tail_products_kernel<BG, MAXT>), dim3(nch, (B + BG - 1) / BG), dim3(cols), lds, s, genes, x, B, G,
+                     a.Wp, a.P, a.W1, a.Hd, chunk_len, ws);
+  return hipGetLastError();
+}
+
+// the split-K products alone: ws[chunk][b][P + Hd]; *nchunks = the number of gene chunks the caller sums over.
+// A batch of at most 4 / 8 cells runs the kernel with that many accumulators per thread.
+hipError_t cell_tail_products(const float* genes, const float* x, int B, int G, const CellTailArgs& a, float* ws,
+                              int* nchunks, hipStream_t s) {
   const int cols = a.P + a.Hd;
   const int slices = (G + CT_KS - 1) / CT_KS, nch = cell_tail_chunks(G);
   const int chunk_len = ((slices + nch - 1) / nch) * CT_KS;
-  const size_t lds = ((size_t)cols * CT_PITCH + 2 * CT_BG * CT_KS) * sizeof(float);
-  static std::atomic<unsigned long long> ready;
-  if (hipError_t e = ensure_dynamic_lds((const void*)cell_tail_products_kernel, lds, ready); e != hipSuccess) return e;
-  Traced tr(K_CELL_TAIL, 2.0 * B * G * cols, s, (double)G * cols * 4 * ((B + CT_BG - 1) / CT_BG) + 2.0 * B * G * 4);
-  hipLaunchKernelGGL(cell_tail_products_kernel, dim3(nch, (B + CT_BG - 1) / CT_BG), dim3(cols), lds, s, genes, x, B, G,
-                     a.Wp, a.P, a.W1, a.Hd, chunk_len, ws);
+  const int groups = B <= 4 ? 1 : B <= 8 ? 1 : (B + CT_BG - 1) / CT_BG;
+  Traced tr(K_CELL_TAIL, 2.0 * B * G * cols, s, (double)G * cols * 4 * groups + 2.0 * B * G * 4);
+  *nchunks = nch;
+  if (cols <= 512) {
+    if (B <= 4) return launch_products<4, 512>(genes, x, B, G, a, ws, nch, chunk_len, s);
+    if (B <= 8) return launch_products<8, 512>(genes, x, B, G, a, ws, nch, chunk_len, s);
+    return launch_products<CT_BG, 512>(genes, x, B, G, a, ws, nch, chunk_len, s);
+  }
+  if (B <= 4) return launch_products<4, 1024>(genes, x, B, G, a, ws, nch, chunk_len, s);
+  if (B <= 8) return launch_products<8, 1024>(genes, x, B, G, a, ws, nch, chunk_len, s);
+  return launch_products<CT_BG, 1024>(genes, x, B, G, a, ws, nch, chunk_len, s);
+}
+
+hipError_t cell_tail(const float* genes, const float* x, int B, int G, CellTailArgs a, float* ws, float* out,
+                     hipStream_t s) {
+  int nch = 0;
+  if (hipError_t e = cell_tail_products(genes, x, B, G, a, ws, &nch, s); e != hipSuccess) return e;
   int threads = a.P > a.Hd ? a.P : a.Hd;
   if (a.O > threads) threads = a.O;
   threads = (threads + 63) / 64 * 64;

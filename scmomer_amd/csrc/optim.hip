@@ -31,22 +31,60 @@ __global__ __launch_bounds__(256) void adam_sqnorm_kernel(const AdamItem* __rest
 
 // One workgroup forms the total norm from the chunk partials in a fixed order (chunk sums per tensor, square root per
 // tensor, squares of those summed, square root) and leaves the clip factor in scal[0] (the norm in scal[1]).
+constexpr int ADAM_LONG = 32;       // a tensor of more chunks than this is summed by the whole workgroup
+constexpr int ADAM_MAX_LONG = 32;   // such tensors the workgroup takes on; further ones go the single-thread way
 __global__ __launch_bounds__(256) void adam_norm_kernel(const AdamItem* __restrict__ items, int nchunks,
                                                         const float* __restrict__ partial, float max_norm,
                                                         float* __restrict__ scal, float* __restrict__ norm_out) {
   __shared__ float ws[4];
-  // thread t walks the chunks t, t + 256, ...; the thread that meets a tensor's FIRST chunk sums that tensor's
-  // consecutive chunks
+  __shared__ int n_long;
+  __shared__ int long_lo[ADAM_MAX_LONG], long_hi[ADAM_MAX_LONG];
+  if (threadIdx.x == 0) n_long = 0;
+  __syncthreads();
+  // thread t walks the chunks t, t + 256, ...; the thread that meets a tensor's FIRST chunk finds its last one (the
+  // chunks of a tensor are consecutive) and sums a short tensor itself
   float acc = 0.f;
   for (int c = threadIdx.x; c < nchunks; c += 256) {
     const int tn_ = items[c].tensor;
     if (c > 0 && items[c - 1].tensor == tn_) continue;   // not the first chunk of its tensor
+    int lo = c, hi = nchunks;                            // first chunk j > c with another tensor number
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (items[mid].tensor == tn_) lo = mid; else hi = mid;
+    }
+    if (hi - c > ADAM_LONG) {
+      const int slot = atomicAdd(&n_long, 1);
+      if (slot < ADAM_MAX_LONG) { long_lo[slot] = c; long_hi[slot] = hi; continue; }
+    }
     float ts = 0.f;
-    for (int j = c; j < nchunks && items[j].tensor == tn_; ++j) ts += partial[j];
+    for (int j = c; j < hi; ++j) ts += partial[j];
     const float tn = sqrtf(ts);
     acc += tn * tn;
   }
+  __syncthreads();
+  const int nl = min(n_long, ADAM_MAX_LONG);
+  if (threadIdx.x == 0)                                  // the long tensors in table order, whoever found them
+    for (int i = 1; i < nl; ++i)
+      for (int j = i; j > 0 && long_lo[j - 1] > long_lo[j]; --j) {
+        const int a = long_lo[j], b = long_hi[j];
+        long_lo[j] = long_lo[j - 1]; long_hi[j] = long_hi[j - 1];
+        long_lo[j - 1] = a; long_hi[j - 1] = b;
+      }
+  __syncthreads();
+  for (int i = 0; i < nl; ++i) {
+    float ts = 0.f;
+    for (int j = long_lo[i] + threadIdx.x; j < long_hi[i]; j += 256) ts += partial[j];
+    ts = wave_sum(ts);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = ts;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float tn = sqrtf((ws[0] + ws[1]) + (ws[2] + ws[3]));
+      acc += tn * tn;
+    }
+  }
   acc = wave_sum(acc);
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -88,7 +88,7 @@ enum KernelId {   // one id per kernel symbol family that a profiler lists separ
   K_WGRAD = 12, K_WGRAD_BIAS, K_WGRAD_REDUCE, K_CAST, K_EMBED_FWD, K_EMBED_BWD, K_LN_FWD, K_LN_BWD, K_HEAD_FWD,
   K_HEAD_BWD, K_COLSUM, K_PREP_OMEGA, K_CTX_FWD, K_CTX_BWD, K_CTX_FINALIZE, K_APPLY_FWD, K_APPLY_BWD_Q,
   K_APPLY_BWD_K, K_KFIX, K_S1_MASK, K_CE, K_BIN, K_OMEGA_QR, K_FEATURE_MAP, K_LINEAR_ATTENTION, K_FFN_CHAIN_FWD,
-  K_REDUCE_BATCH, K_GEMM_LN_BWD, K_GEMM_RES_LN, K_ADAM, K_CELL_TAIL, K_COUNT
+  K_REDUCE_BATCH, K_GEMM_LN_BWD, K_GEMM_RES_LN, K_ADAM, K_CELL_TAIL, K_DISTILL_TAIL, K_COUNT
 };
 void trace_begin(int kid, double flops, double bytes, hipStream_t s);
 void trace_end(int kid, hipStream_t s);
@@ -182,6 +182,18 @@ using CellTailArgs = ::scm_cell_tail_args;
 long cell_tail_ws_floats(int B, int G, int P, int Hd);
 hipError_t cell_tail(const float* genes, const float* x, int B, int G, CellTailArgs a, float* ws, float* out,
                      hipStream_t s);
+hipError_t cell_tail_products(const float* genes, const float* x, int B, int G, const CellTailArgs& a, float* ws,
+                              int* nchunks, hipStream_t s);
+
+// distill_tail.hip
+using DistillArgs = ::scm_distill_args;
+using DistillGrads = ::scm_distill_grads;
+long distill_tape_floats(int B, int P, int Hd, int O);
+long distill_ws_floats(int B, int G, int P, int Hd, int O, int Na);
+int distill_max_cells();
+hipError_t distill_fwd(const DistillArgs& a, float* tape, float* ws, float* losses, hipStream_t s);
+hipError_t distill_bwd(const DistillArgs& a, const float* tape, float* ws, const float* gloss, const DistillGrads& gr,
+                       int accumulate, hipStream_t s);
 
 // s1_tail.hip
 hipError_t s1_mask(const int64_t* tok, const float* rand_pick, const float* rand_replace, int B, int N, float mask_prob,

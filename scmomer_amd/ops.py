@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import AdamItem, CellTailArgs, FavorPlan, FfnFwdArgs, ReduceJob, View4, WgradItem, check, lib
+from ._lib import AdamItem, CellTailArgs, DistillArgs, DistillGrads, FavorPlan, FfnFwdArgs, ReduceJob, View4, WgradItem, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -565,6 +565,78 @@ def cell_tail(genes, x, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo, normalize: bool)
     out = torch.empty((b, o), dtype=F32, device=genes.device)
     check(lib.scm_cell_tail_fwd(_p(genes), _p(x), b, g, C.byref(a), _p(ws), _p(out), _stream()), "scm_cell_tail_fwd")
     return out
+
+
+# ----------------------------------------------------------------------------- distillation tail
+DISTILL_GRAD_ORDER = ("W1", "b1", "ln_w", "ln_b", "W2", "b2", "Wo", "bo", "Wa", "ba", "Wr", "br")
+
+
+def distill_supported(b: int, p: int, hd: int, o: int) -> bool:
+    return cell_tail_supported(p, hd, o) and o == 128 and 0 < b <= lib.scm_distill_max_cells()
+
+
+class DistillCall:
+    """One forward of the S3 tail (scm_distill_fwd) and what its backward needs: the argument block, the tensors it
+    points into, the tape and the scratch."""
+
+    def __init__(self, genes, x, atac_raw, latent, drop, pos_weight, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo,
+                 wa, ba, wr, br, normalize: bool, distill_weight: float = 1.0):
+        tensors = [genes, x, atac_raw, latent, pos_weight, wp, *ln_p, w1, b1, *ln_h, w2, b2, wo, bo, wa, ba, wr, br]
+        if drop is not None:
+            tensors.append(drop)
+        for t in tensors:
+            _req(t, F32, "distill operand")
+        b, g = genes.shape
+        p, hd, o, na = wp.shape[0], w1.shape[0], wo.shape[0], wa.shape[0]
+        if x.shape != genes.shape or wp.shape[1] != g or w1.shape[1] != g or tuple(w2.shape) != (p, hd) or \
+                wo.shape[1] != 2 * p or tuple(wa.shape) != (na, o) or tuple(wr.shape) != (g, o) or \
+                tuple(atac_raw.shape) != (b, na) or tuple(latent.shape) != (b, p) or ba.numel() != na or \
+                br.numel() != g or pos_weight.numel() not in (1, na) or (drop is not None and tuple(drop.shape) != (b, hd)):
+            raise ValueError("distill tail: inconsistent shapes")
+        if not distill_supported(b, p, hd, o):
+            raise ValueError(f"distill tail: unsupported sizes (cells {b}, widths {p}/{hd}/{o})")
+        a = DistillArgs()
+        t = a.tail
+        t.P, t.Hd, t.O, t.normalize = p, hd, o, int(bool(normalize))
+        t.Wp, t.ln_p_w, t.ln_p_b, t.W1, t.b1 = _p(wp), _p(ln_p[0]), _p(ln_p[1]), _p(w1), _p(b1)
+        t.ln_h_w, t.ln_h_b, t.W2, t.b2, t.Wo, t.bo = _p(ln_h[0]), _p(ln_h[1]), _p(w2), _p(b2), _p(wo), _p(bo)
+        a.B, a.G, a.Na, a.pos_weight_n, a.distill_weight = b, g, na, pos_weight.numel(), float(distill_weight)
+        a.Wa, a.ba, a.Wr, a.br = _p(wa), _p(ba), _p(wr), _p(br)
+        a.genes, a.x, a.atac_raw, a.latent, a.drop, a.pos_weight = _p(genes), _p(x), _p(atac_raw), _p(latent), _p(drop), \
+            _p(pos_weight)
+        self.args, self.keep = a, tensors
+        self.shapes = {"W1": w1.shape, "b1": b1.shape, "ln_w": ln_h[0].shape, "ln_b": ln_h[1].shape, "W2": w2.shape,
+                       "b2": b2.shape, "Wo": wo.shape, "bo": bo.shape, "Wa": wa.shape, "ba": ba.shape, "Wr": wr.shape,
+                       "br": br.shape}
+        dev = genes.device
+        self.tape = torch.empty(lib.scm_distill_tape_floats(b, p, hd, o), dtype=F32, device=dev)
+        self.ws = torch.empty(lib.scm_distill_ws_floats(b, g, p, hd, o, na), dtype=F32, device=dev)
+        self.student = self.tape[2 * b * hd:2 * b * hd + b * 2 * p].view(b, 2 * p)[:, :p]   # the student's embedding
+
+    def forward(self) -> torch.Tensor:
+        """-> losses [4] = (BCE, RNA MSE, distillation MSE, BCE + RNA MSE + distill_weight * distillation MSE)"""
+        losses = torch.empty(4, dtype=F32, device=self.tape.device)
+        check(lib.scm_distill_fwd(C.byref(self.args), _p(self.tape), _p(self.ws), _p(losses), _stream()), "scm_distill_fwd")
+        return losses
+
+    def backward(self, gloss: torch.Tensor, grads=None, accumulate: bool = False):
+        """Gradients of gloss . losses for the twelve trainable tensors in DISTILL_GRAD_ORDER: written into fresh
+        tensors (grads None) or written / added into the given ones."""
+        _req(gloss, F32, "distill gloss")
+        if gloss.numel() != 3:
+            raise ValueError("distill tail: gloss holds three values")
+        if grads is None:
+            grads = [torch.empty(tuple(self.shapes[n]), dtype=F32, device=gloss.device) for n in DISTILL_GRAD_ORDER]
+            accumulate = False
+        g = DistillGrads()
+        for n, t in zip(DISTILL_GRAD_ORDER, grads):
+            _req(t, F32, "distill gradient")
+            if t.numel() != int(torch.Size(self.shapes[n]).numel()):
+                raise ValueError(f"distill tail: gradient buffer of {n} has {t.numel()} elements")
+            setattr(g, "d" + n, _p(t))
+        check(lib.scm_distill_bwd(C.byref(self.args), _p(self.tape), _p(self.ws), _p(gloss), C.byref(g),
+                                  int(bool(accumulate)), _stream()), "scm_distill_bwd")
+        return grads
 
 
 # ----------------------------------------------------------------------------- optimizer step

@@ -3,7 +3,10 @@ Performer RNA encoder is frozen but runs in train() mode (its projection redraw 
 performer_pytorch.py:520-534); trainable are the student encoder, to_out and the two linear decoders.  The loss is
 BCE-with-logits on the binarised ATAC target + MSE on the RNA reconstruction + distill_weight * MSE between the
 student's embedding and the precomputed teacher embedding.  The frozen encoder runs on the kernels without a tape;
-the small trainable tail (a few [B, 16906] x [16906, 256] and 128-wide products) is torch library code.
+the trainable tail (two [B, 16906] x [16906, 128/256] products, the narrow middle, the two decoders with their
+losses, and the backward of all of it) runs on its own eight launches (ops.DistillCall) when the model has the
+reference's shape -- student MLP, single-Linear decoders, f32 on the GPU, at most 32 cells -- and as torch library
+code otherwise.
 """
 from __future__ import annotations
 
@@ -36,17 +39,108 @@ def freeze_for_distillation(model) -> Tuple[int, int]:
     return total, sum(p.numel() for p in model.parameters() if p.requires_grad)
 
 
+def _single_linear(dec):
+    seq = getattr(dec, "output_mean", None)
+    if isinstance(seq, nn.Sequential) and len(seq) == 1 and isinstance(seq[0], nn.Linear) and seq[0].bias is not None:
+        return seq[0]
+    return None
+
+
+TAIL_PARAMETERS = ("encoder.encoder.0.weight", "encoder.encoder.0.bias", "encoder.encoder.1.weight",
+                   "encoder.encoder.1.bias", "encoder.encoder.4.weight", "encoder.encoder.4.bias", "to_out.weight",
+                   "to_out.bias", "ATAC.output_mean.0.weight", "ATAC.output_mean.0.bias", "RNA.output_mean.0.weight",
+                   "RNA.output_mean.0.bias")        # in the order of ops.DISTILL_GRAD_ORDER
+
+
+def tail_parameters(model):
+    """The twelve trainable tensors of the tail in the order the kernels take their gradients, or None when the
+    model's tail is not the reference's (student MLP of extract_cell_emb.py:27-40, decoders of utils.py:168-179)."""
+    from .scmomer import StudentEncoder
+    enc = getattr(model.encoder, "encoder", None)
+    atac, rna = _single_linear(model.ATAC), _single_linear(model.RNA)
+    if not isinstance(model.encoder, StudentEncoder) or enc is None or atac is None or rna is None:
+        return None
+    return [enc[0].weight, enc[0].bias, enc[1].weight, enc[1].bias, enc[4].weight, enc[4].bias, model.to_out.weight,
+            model.to_out.bias, atac.weight, atac.bias, rna.weight, rna.bias]
+
+
+def fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weight: float = 1.0):
+    """The kernel call for this batch (the frozen encoder has run: its per-gene output is an operand), or None when
+    the kernels do not apply: another tail than the reference's, a frozen part that wants gradients, tensors that
+    are not f32 on the GPU, more cells than one call takes."""
+    from . import ingest, ops
+    if not (rna.is_cuda and rna.dtype == torch.float32 and rna.dim() == 2 and rna.is_contiguous()):
+        return None
+    tail = tail_parameters(model)
+    if tail is None:
+        return None
+    frozen = list(model.rna_model.parameters()) + [model.rna_projection.weight, model.rna_ln.weight, model.rna_ln.bias]
+    if any(p.requires_grad for p in frozen):
+        return None
+    w1, b1, lw, lb, w2, b2, wo, bo, wa, ba, wr, br = tail
+    p, hd, o = model.rna_projection.weight.shape[0], w1.shape[0], wo.shape[0]
+    ops_in = [atac_raw, latent_real, pos_weight, model.rna_projection.weight, model.rna_ln.weight, model.rna_ln.bias, *tail]
+    if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ops_in):
+        return None
+    if not ops.distill_supported(rna.shape[0], p, hd, o) or model.rna_ln.eps != 1e-5 or model.encoder.encoder[1].eps != 1e-5:
+        return None
+    if tuple(w2.shape) != (p, hd) or wo.shape[1] != 2 * p or tuple(wr.shape) != (rna.shape[1], o) or wa.shape[1] != o or \
+            tuple(atac_raw.shape) != (rna.shape[0], wa.shape[0]) or tuple(latent_real.shape) != (rna.shape[0], p) or \
+            pos_weight.numel() not in (1, wa.shape[0]) or w1.shape[1] != rna.shape[1] or \
+            model.rna_projection.weight.shape[1] != rna.shape[1]:
+        return None
+    drop_layer = model.encoder.encoder[3]
+    drop = None
+    if drop_layer.training and drop_layer.p > 0:      # nn.Dropout's multipliers, drawn as torch draws them
+        drop = nn.functional.dropout(torch.ones((rna.shape[0], hd), device=rna.device), drop_layer.p, True)
+    with torch.no_grad():
+        genes = model.rna_model(ingest.bin_cells(rna, ingest.RULE_SCMOMER, 5)).contiguous()
+    d = lambda t: t.detach()
+    return ops.DistillCall(genes, rna, atac_raw, latent_real, drop, pos_weight, d(model.rna_projection.weight),
+                           (d(model.rna_ln.weight), d(model.rna_ln.bias)), d(w1), d(b1), (d(lw), d(lb)), d(w2), d(b2),
+                           d(wo), d(bo), d(wa), d(ba), d(wr), d(br), normalize=bool(model.config.normalize),
+                           distill_weight=distill_weight)
+
+
+class _DistillTail(torch.autograd.Function):
+    """losses [4] = (BCE, RNA MSE, distillation MSE, their weighted sum) as a function of the twelve tail tensors."""
+
+    @staticmethod
+    def forward(ctx, call, *weights):
+        ctx.call = call
+        return call.forward()
+
+    @staticmethod
+    def backward(ctx, g):
+        w = torch.tensor([1.0, 1.0, float(ctx.call.args.distill_weight)], device=g.device)
+        grads = ctx.call.backward((g[:3] + g[3] * w).float().contiguous())
+        return (None, *[gr.view(shape) for gr, shape in zip(grads, (tuple(ctx.call.shapes[n]) for n in _order()))])
+
+
+def _order():
+    from . import ops
+    return ops.DISTILL_GRAD_ORDER
+
+
 def distillation_losses(model, rna: torch.Tensor, atac_raw: torch.Tensor, latent_real: torch.Tensor,
-                        pos_weight: torch.Tensor, distill_weight: float) -> Dict[str, torch.Tensor]:
+                        pos_weight: torch.Tensor, distill_weight: float, fused: bool = True) -> Dict[str, torch.Tensor]:
     """One forward of s3_pretrain_missing.py:291-307 -> {'atac', 'rna', 'distill', 'total'} (total is the sum the
-    script backpropagates, before the division by grad_acc)."""
-    atac_target = (atac_raw > 0).float()
-    r_atac, r_rna, atac_embeds = model(rna_values=rna, reconstruct=True, mode='one')
-    loss_atac = nn.functional.binary_cross_entropy_with_logits(r_atac, atac_target, pos_weight=pos_weight)
-    loss_rna = nn.functional.mse_loss(r_rna, rna)
-    loss_distill = nn.functional.mse_loss(atac_embeds, latent_real)
+    script backpropagates, before the division by grad_acc).  fused=False keeps the tail on torch's library code."""
+    call = fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weight) if fused else None
+    if call is not None:
+        four = _DistillTail.apply(call, *tail_parameters(model))
+        return {"atac": four[0], "rna": four[1], "distill": four[2], "total": four[3]}
+    else:
+        atac_target = (atac_raw > 0).float()
+        r_atac, r_rna, atac_embeds = model(rna_values=rna, reconstruct=True, mode='one')
+        loss_atac = nn.functional.binary_cross_entropy_with_logits(r_atac, atac_target, pos_weight=pos_weight)
+        loss_rna = nn.functional.mse_loss(r_rna, rna)
+        loss_distill = nn.functional.mse_loss(atac_embeds, latent_real)
     return {"atac": loss_atac, "rna": loss_rna, "distill": loss_distill,
             "total": loss_atac + loss_rna + distill_weight * loss_distill}
+
+
+LOSS_NAMES = ("atac", "rna", "distill", "total")
 
 
 class S3Step:
@@ -59,7 +153,7 @@ class S3Step:
     GPU idle for 40 % of it."""
 
     def __init__(self, model, *, lr: float = 1e-4, grad_acc: int = 1, pos_weight: float = 1.0,
-                 distill_weight: float = 1.0, group=None, use_graph: bool = False):
+                 distill_weight: float = 1.0, group=None, use_graph: bool = False, fused: bool = True):
         from . import dist as sdist
         self.model = model
         self.grad_acc = int(grad_acc)
@@ -78,9 +172,27 @@ class S3Step:
         self.use_graph = use_graph
         self._graph = None
         self._seed = None
+        self.fused = fused
+        self._gloss = None
+        self._adam_table = None
+        tail = tail_parameters(model) if fused else None
+        acc_of = {id(p): a for p, a in zip(self.params, self.accs)}
+        # the kernels' backward adds straight into the accumulators: every tail tensor must be trainable
+        self._tail_accs = [acc_of[id(p)] for p in tail] if tail is not None and all(id(p) in acc_of for p in tail) and \
+            len(self.params) == len(tail) else None
 
-    def _forward_backward(self, rna, atac_raw, latent_real) -> Dict[str, torch.Tensor]:
-        losses = distillation_losses(self.model, rna, atac_raw, latent_real, self.pos_weight, self.distill_weight)
+    def _forward_backward(self, rna, atac_raw, latent_real) -> torch.Tensor:
+        """-> [4] = the losses in the order of LOSS_NAMES"""
+        call = fused_tail_call(self.model, rna, atac_raw, latent_real, self.pos_weight, self.distill_weight) \
+            if self._tail_accs is not None else None
+        if call is not None:
+            if self._gloss is None:
+                self._gloss = torch.tensor([1.0, 1.0, float(self.distill_weight)], device=rna.device) / self.grad_acc
+            four = call.forward()
+            call.backward(self._gloss, grads=self._tail_accs, accumulate=True)
+            return four
+        losses = distillation_losses(self.model, rna, atac_raw, latent_real, self.pos_weight, self.distill_weight,
+                                     fused=self.fused)
         if self.params:
             if self._seed is None:
                 self._seed = torch.full((), 1.0, dtype=losses["total"].dtype, device=losses["total"].device) / self.grad_acc
@@ -88,7 +200,7 @@ class S3Step:
             left = [(a, g) for a, g in zip(self.accs, grads) if g is not None]
             if left:
                 torch._foreach_add_([a for a, _ in left], [g for _, g in left])
-        return {k: v.detach() for k, v in losses.items()}
+        return torch.stack([losses[k].detach() for k in LOSS_NAMES])
 
     def _capture(self, rna, atac_raw, latent_real):
         """Record the micro-step for these shapes once; the projection redraw check stays outside the recording."""
@@ -98,14 +210,10 @@ class S3Step:
         calls = self.performer.calls_since_last_redraw.clone() if self.performer is not None else None
         if self.performer is not None:
             self.performer.auto_check_redraw = False
-        self._static_out: Dict[str, torch.Tensor] = {}
+        self._static_out = torch.zeros(len(LOSS_NAMES), device=rna.device)
 
         def body():
-            out = self._forward_backward(*self._static_in)
-            for k, v in out.items():
-                if k not in self._static_out:
-                    self._static_out[k] = torch.zeros_like(v)
-                self._static_out[k].copy_(v)
+            self._static_out.copy_(self._forward_backward(*self._static_in))
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -124,6 +232,27 @@ class S3Step:
         self._graph, self._graph_auto = graph, auto
         self._graph_shapes = tuple(tuple(t.shape) for t in self._static_in)
 
+    def _kernel_optimizer_step(self) -> bool:
+        """Rank sum, clip to 1e4, Adam and the zeroing of the accumulators in the three launches of the optimizer
+        kernel (on torch.optim.Adam's own state; from the second optimizer step on, torch creates the moments in
+        its first).  False: not applicable, the caller runs torch's."""
+        from . import ops
+        from .train import adam_state_for_kernel
+        state = adam_state_for_kernel(self.optimizer, self.params) if self.fused else None
+        if state is None:
+            return False
+        ms, vs, steps = state
+        if self._adam_table is None or not self._adam_table.matches(self.params, self.accs, ms, vs):
+            self._adam_table = ops.AdamTable(self.params, self.accs, ms, vs)
+        self.averager.sum_in_place_()
+        for st in steps:
+            st += 1
+        g = self.optimizer.param_groups[0]
+        ops.adam_step(self._adam_table, step=int(steps[0]), lr=float(g["lr"]), beta1=g["betas"][0], beta2=g["betas"][1],
+                      eps=g["eps"], max_norm=1e4, grad_scale=1.0 / self.averager.world)
+        torch.autograd.graph.increment_version(self.params)
+        return True
+
     def micro_step(self, rna, atac_raw, latent_real) -> Dict[str, torch.Tensor]:
         self.index += 1
         shapes = (tuple(rna.shape), tuple(atac_raw.shape), tuple(latent_real.shape))
@@ -138,12 +267,15 @@ class S3Step:
             for dst, src in zip(self._static_in, (rna, atac_raw, latent_real)):
                 dst.copy_(src)
             self._graph.replay()
-            losses = {k: v.clone() for k, v in self._static_out.items()}
+            four = self._static_out.clone()
         else:
             if self._graph is not None and self.performer is not None and self._graph_auto:
                 self.performer.check_redraw_projections()    # the model's own check is off while a recording exists
-            losses = self._forward_backward(rna, atac_raw, latent_real)
+            four = self._forward_backward(rna, atac_raw, latent_real)
+        losses = {k: four[i] for i, k in enumerate(LOSS_NAMES)}
         if self.index % self.grad_acc == 0:
+            if self._kernel_optimizer_step():
+                return losses
             for p, a in zip(self.params, self.accs):
                 p.grad = a
             if self.averager is not None:

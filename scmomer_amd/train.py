@@ -208,6 +208,27 @@ class _Recorded:
         self.graph, self.static_in, self.static_out = graph, static_in, static_out
 
 
+def adam_state_for_kernel(opt, params):
+    """(exp_avgs, exp_avg_sqs, steps) of torch.optim.Adam for the given trainable parameters, or None when the step
+    cannot go through the optimizer kernel: parameters off the GPU or not f32, an Adam variant the kernel does not
+    implement, or moments that do not exist yet (torch creates them in its first step)."""
+    if not params or not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+        return None
+    if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    if g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or \
+            g.get("differentiable") or isinstance(g["lr"], torch.Tensor):
+        return None
+    ms, vs, steps = [], [], []
+    for p in params:
+        st = opt.state.get(p)
+        if not st or "exp_avg" not in st or not st["exp_avg"].is_cuda:
+            return None
+        ms.append(st["exp_avg"]), vs.append(st["exp_avg_sq"]), steps.append(st["step"])
+    return ms, vs, steps
+
+
 class S1Trainer:
     """Owns optimizer, schedule, gradient accumulators and the data-parallel exchange for one model replica.
 
@@ -330,26 +351,7 @@ class S1Trainer:
         return loss.detach(), s1_cell_accuracy(logits.detach(), labels, self.pad_id).view(groups, b).mean(dim=1)
 
     def _fused_tail_state(self):
-        """(exp_avgs, exp_avg_sqs, steps) of torch.optim.Adam for the trainable parameters, or None when the step
-        cannot go through the optimizer kernel: parameters off the GPU or not f32, an Adam variant the
-        kernel does not implement, or moments that do not exist yet (torch creates them in its first step)."""
-        if not self.fused_optimizer or not self.params or not all(p.is_cuda and p.dtype == torch.float32 and
-                                                                  p.is_contiguous() for p in self.params):
-            return None
-        opt = self.optimizer
-        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
-            return None
-        g = opt.param_groups[0]
-        if g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or \
-                g.get("differentiable") or isinstance(g["lr"], torch.Tensor):
-            return None
-        ms, vs, steps = [], [], []
-        for p in self.params:
-            st = opt.state.get(p)
-            if not st or "exp_avg" not in st or not st["exp_avg"].is_cuda:
-                return None
-            ms.append(st["exp_avg"]), vs.append(st["exp_avg_sq"]), steps.append(st["step"])
-        return ms, vs, steps
+        return adam_state_for_kernel(self.optimizer, self.params) if self.fused_optimizer else None
 
     def _optimizer_step(self):
         """The sync micro-step's tail (s1_pretrain_rna.py:299-305): average over ranks, clip, Adam, zero.  On the GPU

@@ -205,3 +205,115 @@ def test_cell_embedding_tail_kernel_equals_the_torch_tail(cells, genes, normaliz
     m.eval()
     with torch.enable_grad():
         assert m._tail_operands(x) is None                  # gradients wanted: torch's tail
+
+
+@pytest.mark.parametrize("cells,genes,peaks,dropout,per_peak_weight",
+                         [(3, 16906, 20000, True, False), (5, 1000, 777, False, True), (17, 515, 130, True, False),
+                          (32, 333, 64, True, True), (1, 70, 3, False, False)])
+def test_distillation_tail_kernels_equal_the_torch_tail(cells, genes, peaks, dropout, per_peak_weight):
+    """The S3 tail (s3_pretrain_missing.py:291-307 after the frozen encoder: student MLP, to_out, the two linear
+    decoders, BCE-with-logits with pos_weight + two MSE losses) and its backward as the eight launches of
+    ops.DistillCall against the same layers and losses under torch autograd in f32, on random operands, with the
+    same dropout multipliers.  Sums of up to 16,906 f32 terms in another order: losses to 2e-6 relative, every
+    gradient to 2e-5 of its largest entry; then the accumulating form adds the same gradients to what is there."""
+    from scmomer_amd import ops
+    torch.manual_seed(100 + cells)
+    P, Hd, Ow = 128, 256, 128
+    r = lambda *s, sc=1.0: (torch.randn(s, device=DEV) * sc)
+    wp, w1, b1 = r(P, genes, sc=0.05), r(Hd, genes, sc=0.05), r(Hd, sc=0.1)
+    ln_p, ln_h = (1 + r(P, sc=0.3), r(P, sc=0.3)), (1 + r(Hd, sc=0.3), r(Hd, sc=0.3))
+    w2, b2, wo, bo = r(P, Hd, sc=0.1), r(P, sc=0.1), r(Ow, 2 * P, sc=0.1), r(Ow, sc=0.1)
+    wa, ba, wr, br = r(peaks, Ow, sc=0.1), r(peaks, sc=0.1), r(genes, Ow, sc=0.1), r(genes, sc=0.1)
+    gene_scores = torch.relu(r(cells, genes))
+    x = ((torch.rand((cells, genes), device=DEV) < 0.2) * torch.rand((cells, genes), device=DEV) * 6).contiguous()
+    atac_raw = ((torch.rand((cells, peaks), device=DEV) < 0.1) * 3.0).contiguous()
+    latent = r(cells, P)
+    pos_weight = (1 + torch.rand(peaks, device=DEV) * 3) if per_peak_weight else torch.tensor([2.5], device=DEV)
+    drop = torch.nn.functional.dropout(torch.ones((cells, Hd), device=DEV), 0.1, True) if dropout else None
+    gloss = torch.tensor([0.7, 1.3, 0.45], device=DEV)
+
+    leaves = [t.clone().requires_grad_() for t in (w1, b1, ln_h[0], ln_h[1], w2, b2, wo, bo, wa, ba, wr, br)]
+    tw1, tb1, tlw, tlb, tw2, tb2, two, tbo, twa, tba, twr, tbr = leaves
+    f = gene_scores @ wp.t()
+    f = f / f.norm(dim=-1, keepdim=True)
+    rr = torch.nn.functional.layer_norm(f, (P,), ln_p[0], ln_p[1])
+    h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x @ tw1.t() + tb1, (Hd,), tlw, tlb))
+    if drop is not None:
+        h = h * drop
+    a = h @ tw2.t() + tb2
+    out = torch.cat([a, rr], 1) @ two.t() + tbo
+    want = torch.stack([
+        torch.nn.functional.binary_cross_entropy_with_logits(out @ twa.t() + tba, (atac_raw > 0).float(),
+                                                             pos_weight=pos_weight),
+        torch.nn.functional.mse_loss(out @ twr.t() + tbr, x), torch.nn.functional.mse_loss(a, latent)])
+    (want * gloss).sum().backward()
+
+    call = ops.DistillCall(gene_scores, x, atac_raw, latent, drop, pos_weight, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo,
+                           wa, ba, wr, br, normalize=True, distill_weight=0.3)
+    got = call.forward()
+    assert float(((got[:3] - want).abs() / want.abs()).max()) <= 2e-6, (got, want)
+    assert abs(float(got[3]) - float(want[0] + want[1] + 0.3 * want[2])) <= 2e-6 * float(got[3])
+    assert float((call.student - a).abs().max()) <= 2e-5 * float(a.abs().max())
+    grads = call.backward(gloss)
+    worst = 0.0
+    for name, g, leaf in zip(ops.DISTILL_GRAD_ORDER, grads, leaves):
+        e = float((g.view_as(leaf) - leaf.grad).abs().max()) / float(leaf.grad.abs().max())
+        worst = max(worst, e)
+        assert e <= 2e-5, f"{name}: {e:.3e}"
+    print(f"distillation tail, {cells} cells x {genes} genes x {peaks} peaks: worst gradient error {worst:.2e} of max")
+    base = [torch.full_like(g, 0.25) for g in grads]
+    call2 = ops.DistillCall(gene_scores, x, atac_raw, latent, drop, pos_weight, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo,
+                            wa, ba, wr, br, normalize=True)
+    call2.forward()
+    call2.backward(gloss, grads=base, accumulate=True)
+    for name, acc, g in zip(ops.DISTILL_GRAD_ORDER, base, grads):
+        assert torch.equal(acc, g + 0.25), name
+
+
+def test_s3_step_on_the_tail_kernels_follows_the_torch_tail(S, monkeypatch):
+    """Two optimizer steps of two micro-steps with the tail on its kernels (forward, backward into the gradient
+    accumulators, optimizer kernel) against the same steps with the tail and the optimizer on torch's library
+    code, dropout p = 0.1 with the same multipliers in both: same losses to 1e-5, weights within 2 % of the
+    distance they moved."""
+    from scmomer_amd import s3
+    n_peaks, bsz = 3000, 3
+    p = O.make_scmomer_params(6)
+    rng = np.random.default_rng(80)
+    t = lambda *s_, sc=0.05: torch.from_numpy((rng.standard_normal(s_) * sc).astype(np.float32))
+    dec = {"RNA.output_mean.0.weight": t(N, 128), "RNA.output_mean.0.bias": t(N),
+           "ATAC.output_mean.0.weight": t(n_peaks, 128), "ATAC.output_mean.0.bias": t(n_peaks)}
+    batches = [(torch.from_numpy(O.synthetic_cells(81 + i, bsz, N)).to(DEV),
+                torch.from_numpy((rng.random((bsz, n_peaks)) < 0.05).astype(np.float32)).to(DEV),
+                t(bsz, 128, sc=1.0).to(DEV)) for i in range(4)]
+    keep = torch.nn.functional.dropout(torch.ones((bsz, 256), device=DEV), 0.1, True)
+    monkeypatch.setattr(torch.nn.functional, "dropout", lambda x, p=0.5, training=True, inplace=False: x * keep)
+    results = []
+    for fused in (False, True):
+        cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+        m = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(N, 128, dropout=0.1),
+                      rna_decoder=s3.ReconstructNet(N, 128), atac_decoder=s3.ReconstructNet(n_peaks, 128))
+        m.load_state_dict({**p, **dec}, strict=False)
+        m = m.to(DEV)
+        s3.freeze_for_distillation(m)
+        m.train()
+        m.rna_model.model.performer.fix_projection_matrices_()
+        step = s3.S3Step(m, lr=1e-3, grad_acc=2, pos_weight=2.0, distill_weight=0.5, fused=fused)
+        assert (step._tail_accs is not None) == fused
+        start = {k: v.detach().clone() for k, v in m.named_parameters()}
+        losses = [{k: float(v) for k, v in step.micro_step(*b).items()} for b in batches]
+        results.append((losses, start, {k: v.detach().clone() for k, v in m.named_parameters()}))
+        assert (step._adam_table is not None) == fused        # the second optimizer step ran on the kernel
+    (l0, start, w0), (l1, _, w1) = results
+    for a, b in zip(l0, l1):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * abs(a[k]), (k, a[k], b[k])
+    worst = 0.0
+    for k in w0:
+        moved = float((w0[k] - start[k]).abs().max())
+        if moved == 0:
+            assert torch.equal(w0[k], w1[k]), k
+            continue
+        e = float((w0[k] - w1[k]).abs().max()) / moved
+        worst = max(worst, e)
+        assert e <= 2e-2, f"{k}: {e:.3e}"
+    print(f"S3 on the tail kernels vs torch tail after 2 optimizer steps: worst weight difference {worst:.2e} of the move")
