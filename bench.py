@@ -287,42 +287,48 @@ def run_s3(args, world, rank, device):
     s3.freeze_for_distillation(model)
     model.rna_model.model.fix_projection_matrices_()
     model = model.to(device).train()
+    window = args.window if args.window else 1
+    if args.grad_acc % window:
+        raise SystemExit("--window must divide --grad-acc")
     stepper = s3.S3Step(model, lr=1e-4, grad_acc=args.grad_acc, pos_weight=1.0, distill_weight=1.0,
                         use_graph=not args.eager)
     gen = torch.Generator().manual_seed(100 + rank)
+    cells = batch * window
     data = []
     for _ in range(2):
-        rna = ((torch.rand((batch, N_GENES), generator=gen) < 0.15) *
-               torch.distributions.Gamma(2.0, 1 / 1.2).sample((batch, N_GENES))).float().to(device)
-        atac = (torch.rand((batch, n_peaks), generator=gen) < 0.05).float().to(device)
-        latent = torch.randn((batch, 128), generator=gen).to(device)
+        rna = ((torch.rand((cells, N_GENES), generator=gen) < 0.15) *
+               torch.distributions.Gamma(2.0, 1 / 1.2).sample((cells, N_GENES))).float().to(device)
+        atac = (torch.rand((cells, n_peaks), generator=gen) < 0.05).float().to(device)
+        latent = torch.randn((cells, 128), generator=gen).to(device)
         data.append((rna, atac, latent))
-    for i in range(max(args.warmup, 1)):
-        losses = stepper.micro_step(*data[i % 2])
+    one = (lambda d: stepper.micro_step(*d)) if window == 1 else (lambda d: stepper.window_step(*d, window))
+    for i in range(max(args.warmup, 2 * args.grad_acc // window)):    # past torch's first optimizer step
+        losses = one(data[i % 2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        losses = stepper.micro_step(*data[i % 2])
+        losses = one(data[i % 2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = sdist.max_over_ranks(time.perf_counter() - t0, device)
     if rank == 0:
-        value = world * batch * args.steps / dt
+        value = world * cells * args.steps / dt
         print(json.dumps({
             "metric": "cells/sec, S3 distillation step (frozen Performer forward + trainable tail fwd/bwd, 16.9k genes)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "scMomer.forward(mode='one', reconstruct=True), train mode, frozen encoder; BCE + "
-                                   "MSE + distillation loss; backward; clip + Adam every grad_acc steps",
-                       "cells_per_gpu_per_step": batch, "gene_tokens": N_GENES, "atac_peaks": n_peaks, "depth": 6,
+                                   "MSE + distillation loss; backward; clip + Adam every grad_acc micro-steps",
+                       "cells_per_gpu_per_step": cells, "micro_batch_cells": batch,
+                       "micro_steps_per_launch_chain": window, "gene_tokens": N_GENES, "atac_peaks": n_peaks, "depth": 6,
                        "dim": 200, "heads": 10, "nb_features": 266, "grad_acc": args.grad_acc,
                        "parallelism": f"dp{world}", "launch": "eager" if args.eager else "graph replay"},
-            "final_losses": {k: float(v.item()) for k, v in losses.items()},
+            "final_losses": {k: [float(x) for x in v.reshape(-1)] for k, v in losses.items()},
             "redraw_counter": int(model.rna_model.model.performer.calls_since_last_redraw),
             "roofline": {"whole_step_frac_of_mfma_peak": value / world * 307.52e9 / 1e12 / PEAK_BF16_TFLOPS},
             "cpu_baseline": None}))

@@ -64,9 +64,25 @@ def tail_parameters(model):
             model.to_out.bias, atac.weight, atac.bias, rna.weight, rna.bias]
 
 
-def fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weight: float = 1.0):
-    """The kernel call for this batch (the frozen encoder has run: its per-gene output is an operand), or None when
-    the kernels do not apply: another tail than the reference's, a frozen part that wants gradients, tensors that
+def encoder_scores(model, rna, group_cells=None):
+    """The frozen encoder's per-gene output [cells, genes] (scmomer.py:56,124-126; no tape).  group_cells: `rna` is
+    several batches of that many cells stacked; each keeps the key stabiliser of its own forward call."""
+    from . import ingest
+    performer = getattr(getattr(model.rna_model, "model", None), "performer", None)
+    old = getattr(performer, "stabiliser_group_cells", None)
+    if performer is not None:
+        performer.stabiliser_group_cells = group_cells
+    try:
+        with torch.no_grad():
+            return model.rna_model(ingest.bin_cells(rna, ingest.RULE_SCMOMER, 5)).contiguous()
+    finally:
+        if performer is not None:
+            performer.stabiliser_group_cells = old
+
+
+def fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weight: float = 1.0, genes=None):
+    """The kernel call for this batch (the frozen encoder runs here unless its per-gene output `genes` is given), or
+    None when the kernels do not apply: another tail than the reference's, a frozen part that wants gradients, tensors that
     are not f32 on the GPU, more cells than one call takes."""
     from . import ingest, ops
     if not (rna.is_cuda and rna.dtype == torch.float32 and rna.dim() == 2 and rna.is_contiguous()):
@@ -93,8 +109,8 @@ def fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weigh
     drop = None
     if drop_layer.training and drop_layer.p > 0:      # nn.Dropout's multipliers, drawn as torch draws them
         drop = nn.functional.dropout(torch.ones((rna.shape[0], hd), device=rna.device), drop_layer.p, True)
-    with torch.no_grad():
-        genes = model.rna_model(ingest.bin_cells(rna, ingest.RULE_SCMOMER, 5)).contiguous()
+    if genes is None:
+        genes = encoder_scores(model, rna)
     d = lambda t: t.detach()
     return ops.DistillCall(genes, rna, atac_raw, latent_real, drop, pos_weight, d(model.rna_projection.weight),
                            (d(model.rna_ln.weight), d(model.rna_ln.bias)), d(w1), d(b1), (d(lw), d(lb)), d(w2), d(b2),
@@ -147,10 +163,11 @@ class S3Step:
     """Optimizer-step bookkeeping of the S3 loop (:296-316): loss / grad_acc, backward on every micro-step; every
     grad_acc-th one averages the gradients over the ranks (one flat all-reduce instead of DDP's hooks), clips to
     1e4 and applies Adam (all parameters are handed to Adam, as in the script; frozen ones never get a gradient).
-    Gradients are folded into static accumulators (the slices of the all-reduce bucket), which lets the micro-step
-    (forward, losses, backward, accumulate: about 150 launches, a third of them library calls of the small tail) be
-    recorded once into a HIP graph and replayed (use_graph=True): driven from Python the step is launch-bound, the
-    GPU idle for 40 % of it."""
+    Gradients are folded into static accumulators (the slices of the all-reduce bucket: the tail kernels add into
+    them directly), which lets the micro-step (forward, losses, backward, accumulate) be recorded once into a HIP
+    graph and replayed (use_graph=True).  window_step runs several micro-steps of an accumulation window as one
+    launch chain: the frozen encoder once over all their cells, the tail per micro-batch.  fused=False keeps the
+    tail and the optimizer step on torch's library code."""
 
     def __init__(self, model, *, lr: float = 1e-4, grad_acc: int = 1, pos_weight: float = 1.0,
                  distill_weight: float = 1.0, group=None, use_graph: bool = False, fused: bool = True):
@@ -170,7 +187,8 @@ class S3Step:
             self.performer.redraw_sync = lambda perf: sdist.broadcast_projections(perf, src=0, group=group)
         self.index = 0
         self.use_graph = use_graph
-        self._graph = None
+        self._recorded = {}
+        self._graph_auto = None
         self._seed = None
         self.fused = fused
         self._gloss = None
@@ -181,18 +199,48 @@ class S3Step:
         self._tail_accs = [acc_of[id(p)] for p in tail] if tail is not None and all(id(p) in acc_of for p in tail) and \
             len(self.params) == len(tail) else None
 
-    def _forward_backward(self, rna, atac_raw, latent_real) -> torch.Tensor:
-        """-> [4] = the losses in the order of LOSS_NAMES"""
-        call = fused_tail_call(self.model, rna, atac_raw, latent_real, self.pos_weight, self.distill_weight) \
-            if self._tail_accs is not None else None
-        if call is not None:
+    def _forward_backward(self, rna, atac_raw, latent_real, groups: int = 1) -> torch.Tensor:
+        """-> [groups, 4]: per micro-batch the losses in the order of LOSS_NAMES.  groups > 1 (tail kernels only): the
+        inputs are that many micro-batches stacked; the frozen encoder runs once over all of them with one key
+        stabiliser per micro-batch, the tail once per micro-batch."""
+        b = rna.shape[0] // groups
+        if self._tail_accs is not None:
             if self._gloss is None:
                 self._gloss = torch.tensor([1.0, 1.0, float(self.distill_weight)], device=rna.device) / self.grad_acc
-            four = call.forward()
-            call.backward(self._gloss, grads=self._tail_accs, accumulate=True)
-            return four
+            genes = encoder_scores(self.model, rna, b if groups > 1 else None)
+            calls = [fused_tail_call(self.model, rna[g * b:(g + 1) * b], atac_raw[g * b:(g + 1) * b],
+                                     latent_real[g * b:(g + 1) * b], self.pos_weight, self.distill_weight,
+                                     genes=genes[g * b:(g + 1) * b]) for g in range(groups)]
+            if all(c is not None for c in calls):
+                out = []
+                for call in calls:
+                    out.append(call.forward())
+                    call.backward(self._gloss, grads=self._tail_accs, accumulate=True)
+                return torch.stack(out)
+            if groups > 1:
+                raise RuntimeError("S3 windows need the tail kernels (f32 GPU tensors, at most 32 cells per micro-batch)")
+            # the encoder has ticked its redraw counter for this call already: torch's tail on its output
+            return self._torch_tail(genes, rna, atac_raw, latent_real).view(1, -1)
+        if groups > 1:
+            raise RuntimeError("S3 windows need the tail kernels (the reference's tail with all of it trainable)")
         losses = distillation_losses(self.model, rna, atac_raw, latent_real, self.pos_weight, self.distill_weight,
-                                     fused=self.fused)
+                                     fused=False)
+        return self._backward(losses).view(1, -1)
+
+    def _torch_tail(self, genes, rna, atac_raw, latent_real) -> torch.Tensor:
+        m = self.model
+        feat = m.rna_projection(genes)
+        if m.config.normalize:
+            feat = feat / feat.norm(dim=-1, keepdim=True)
+        student = m.encoder(rna)
+        out = m.to_out(torch.cat([student, m.rna_ln(feat)], 1))
+        l_atac = nn.functional.binary_cross_entropy_with_logits(m.ATAC(out), (atac_raw > 0).float(), pos_weight=self.pos_weight)
+        l_rna = nn.functional.mse_loss(m.RNA(out), rna)
+        l_dis = nn.functional.mse_loss(student, latent_real)
+        return self._backward({"atac": l_atac, "rna": l_rna, "distill": l_dis,
+                               "total": l_atac + l_rna + self.distill_weight * l_dis})
+
+    def _backward(self, losses) -> torch.Tensor:
         if self.params:
             if self._seed is None:
                 self._seed = torch.full((), 1.0, dtype=losses["total"].dtype, device=losses["total"].device) / self.grad_acc
@@ -202,18 +250,19 @@ class S3Step:
                 torch._foreach_add_([a for a, _ in left], [g for _, g in left])
         return torch.stack([losses[k].detach() for k in LOSS_NAMES])
 
-    def _capture(self, rna, atac_raw, latent_real):
-        """Record the micro-step for these shapes once; the projection redraw check stays outside the recording."""
-        self._static_in = [rna.clone(), atac_raw.clone(), latent_real.clone()]
+    def _capture(self, rna, atac_raw, latent_real, groups: int):
+        """Record the launch chain for these shapes once; the projection redraw check stays outside the recording."""
+        static_in = [rna.clone(), atac_raw.clone(), latent_real.clone()]
+        static_out = torch.zeros((groups, len(LOSS_NAMES)), device=rna.device)
         saved = [a.clone() for a in self.accs]
-        auto = self.performer.auto_check_redraw if self.performer is not None else None
         calls = self.performer.calls_since_last_redraw.clone() if self.performer is not None else None
         if self.performer is not None:
+            if not self._recorded:
+                self._graph_auto = self.performer.auto_check_redraw
             self.performer.auto_check_redraw = False
-        self._static_out = torch.zeros(len(LOSS_NAMES), device=rna.device)
 
         def body():
-            self._static_out.copy_(self._forward_backward(*self._static_in))
+            static_out.copy_(self._forward_backward(*static_in, groups))
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -229,8 +278,70 @@ class S3Step:
             a.copy_(s_)
         if calls is not None:
             self.performer.calls_since_last_redraw.copy_(calls)
-        self._graph, self._graph_auto = graph, auto
-        self._graph_shapes = tuple(tuple(t.shape) for t in self._static_in)
+        rec = (graph, static_in, static_out)
+        self._recorded[(tuple(rna.shape), tuple(atac_raw.shape), tuple(latent_real.shape), groups)] = rec
+        return rec
+
+    def _run(self, rna, atac_raw, latent_real, groups: int) -> torch.Tensor:
+        perf = self.performer
+        if self.use_graph and rna.is_cuda:
+            key = (tuple(rna.shape), tuple(atac_raw.shape), tuple(latent_real.shape), groups)
+            graph, static_in, static_out = self._recorded.get(key) or self._capture(rna, atac_raw, latent_real, groups)
+            if perf is not None and self._graph_auto:
+                for _ in range(groups):                      # one tick of the redraw counter per micro-step
+                    perf.check_redraw_projections()          # host-side bookkeeping; a redraw needs fresh copies
+                from . import stack
+                stack.refresh_weights(self.model.rna_model.model)
+            for dst, src in zip(static_in, (rna, atac_raw, latent_real)):
+                dst.copy_(src)
+            graph.replay()
+            return static_out.clone()
+        if perf is not None and self._recorded and self._graph_auto:
+            for _ in range(groups):                          # the model's own check is off while a recording exists
+                perf.check_redraw_projections()
+        elif perf is not None and groups > 1 and perf.auto_check_redraw:
+            for _ in range(groups - 1):                      # the encoder's forward ticks once itself
+                perf.check_redraw_projections()
+        return self._forward_backward(rna, atac_raw, latent_real, groups)
+
+    def _after(self) -> None:
+        if self.index % self.grad_acc == 0:
+            if self._kernel_optimizer_step():
+                return
+            for p, a in zip(self.params, self.accs):
+                p.grad = a
+            if self.averager is not None:
+                self.averager.average_()
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), int(1e4))
+            self.optimizer.step()
+            if self.accs:
+                torch._foreach_zero_(self.accs)
+            for p in self.params:
+                p.grad = None
+
+    def micro_step(self, rna, atac_raw, latent_real) -> Dict[str, torch.Tensor]:
+        """One pass of s3_pretrain_missing.py:291-316 over a batch -> the four losses as device scalars."""
+        self.index += 1
+        four = self._run(rna, atac_raw, latent_real, 1)[0]
+        self._after()
+        return {k: four[i] for i, k in enumerate(LOSS_NAMES)}
+
+    def window_step(self, rna, atac_raw, latent_real, groups: int) -> Dict[str, torch.Tensor]:
+        """``groups`` consecutive micro-steps as one launch chain: the inputs are the micro-batches stacked along
+        dim 0 in the order the loop would have met them -> the four losses per micro-batch, device vectors [groups].
+        Every micro-batch gets what its own micro-step would have given it (own key stabiliser in the frozen encoder,
+        own loss means, own dropout draw); the window must not straddle an optimizer step; a projection redraw that
+        falls due inside a window happens before the whole window."""
+        groups = int(groups)
+        if groups < 1 or rna.shape[0] % groups:
+            raise ValueError(f"{rna.shape[0]} cells do not split into {groups} micro-batches")
+        if self.index % self.grad_acc + groups > self.grad_acc:
+            raise ValueError(f"a window of {groups} micro-steps starting at micro-step {self.index} would straddle the "
+                             f"optimizer step (grad_acc {self.grad_acc})")
+        self.index += groups
+        out = self._run(rna, atac_raw, latent_real, groups)
+        self._after()
+        return {k: out[:, i] for i, k in enumerate(LOSS_NAMES)}
 
     def _kernel_optimizer_step(self) -> bool:
         """Rank sum, clip to 1e4, Adam and the zeroing of the accumulators in the three launches of the optimizer
@@ -252,38 +363,3 @@ class S3Step:
                       eps=g["eps"], max_norm=1e4, grad_scale=1.0 / self.averager.world)
         torch.autograd.graph.increment_version(self.params)
         return True
-
-    def micro_step(self, rna, atac_raw, latent_real) -> Dict[str, torch.Tensor]:
-        self.index += 1
-        shapes = (tuple(rna.shape), tuple(atac_raw.shape), tuple(latent_real.shape))
-        if self.use_graph and rna.is_cuda:
-            if self._graph is None:
-                self._capture(rna, atac_raw, latent_real)
-        if self._graph is not None and shapes == self._graph_shapes:
-            if self.performer is not None and self._graph_auto:
-                self.performer.check_redraw_projections()    # host-side bookkeeping; a redraw needs fresh copies
-                from . import stack
-                stack.refresh_weights(self.model.rna_model.model)
-            for dst, src in zip(self._static_in, (rna, atac_raw, latent_real)):
-                dst.copy_(src)
-            self._graph.replay()
-            four = self._static_out.clone()
-        else:
-            if self._graph is not None and self.performer is not None and self._graph_auto:
-                self.performer.check_redraw_projections()    # the model's own check is off while a recording exists
-            four = self._forward_backward(rna, atac_raw, latent_real)
-        losses = {k: four[i] for i, k in enumerate(LOSS_NAMES)}
-        if self.index % self.grad_acc == 0:
-            if self._kernel_optimizer_step():
-                return losses
-            for p, a in zip(self.params, self.accs):
-                p.grad = a
-            if self.averager is not None:
-                self.averager.average_()
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), int(1e4))
-            self.optimizer.step()
-            if self.accs:
-                torch._foreach_zero_(self.accs)
-            for p in self.params:
-                p.grad = None
-        return losses

@@ -317,3 +317,47 @@ def test_s3_step_on_the_tail_kernels_follows_the_torch_tail(S, monkeypatch):
         worst = max(worst, e)
         assert e <= 2e-2, f"{k}: {e:.3e}"
     print(f"S3 on the tail kernels vs torch tail after 2 optimizer steps: worst weight difference {worst:.2e} of the move")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_s3_window_of_micro_steps_equals_the_micro_steps(S, monkeypatch, use_graph):
+    """window_step over two stacked micro-batches (one launch chain: the frozen encoder once over six cells with a
+    key stabiliser per three, the tail kernels per micro-batch) == two micro_steps, bit for bit: losses per
+    micro-batch, the weights after two optimizer steps, and the redraw counter."""
+    from scmomer_amd import s3
+    n_peaks, bsz = 1000, 3
+    p = O.make_scmomer_params(6)
+    rng = np.random.default_rng(90)
+    t = lambda *s_, sc=0.05: torch.from_numpy((rng.standard_normal(s_) * sc).astype(np.float32))
+    dec = {"RNA.output_mean.0.weight": t(N, 128), "RNA.output_mean.0.bias": t(N),
+           "ATAC.output_mean.0.weight": t(n_peaks, 128), "ATAC.output_mean.0.bias": t(n_peaks)}
+    batches = [(torch.from_numpy(O.synthetic_cells(91 + i, bsz, N)).to(DEV),
+                torch.from_numpy((rng.random((bsz, n_peaks)) < 0.05).astype(np.float32)).to(DEV),
+                t(bsz, 128, sc=1.0).to(DEV)) for i in range(4)]
+    keep = torch.nn.functional.dropout(torch.ones((bsz, 256), device=DEV), 0.1, True)
+    monkeypatch.setattr(torch.nn.functional, "dropout", lambda x, p=0.5, training=True, inplace=False: x * keep)
+    results = []
+    for window in (1, 2):
+        cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
+        m = S.scMomer(cfg, atac_config=None, encoder=S.StudentEncoder(N, 128, dropout=0.1),
+                      rna_decoder=s3.ReconstructNet(N, 128), atac_decoder=s3.ReconstructNet(n_peaks, 128))
+        m.load_state_dict({**p, **dec}, strict=False)
+        m = m.to(DEV)
+        s3.freeze_for_distillation(m)
+        m.train()
+        m.rna_model.model.performer.fix_projection_matrices_()
+        step = s3.S3Step(m, lr=1e-3, grad_acc=2, pos_weight=2.0, distill_weight=0.5, use_graph=use_graph)
+        if window == 1:
+            losses = torch.stack([step.micro_step(*b)["total"] for b in batches])
+        else:
+            stacked = [tuple(torch.cat([batches[i][j], batches[i + 1][j]]) for j in range(3)) for i in (0, 2)]
+            losses = torch.cat([step.window_step(*b, 2)["total"] for b in stacked])
+            with pytest.raises(ValueError):
+                step.micro_step(*batches[0]), step.window_step(*stacked[0], 2)      # would straddle the optimizer step
+        results.append((losses.clone(), {k: v.detach().clone() for k, v in m.named_parameters()},
+                        int(m.rna_model.model.performer.calls_since_last_redraw)))
+    (l0, w0, c0), (l1, w1, c1) = results
+    assert torch.equal(l0, l1), (l0, l1)
+    assert c0 == 4 and c1 == 5                      # the refused window never ran; the extra micro_step before it did
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
