@@ -63,6 +63,17 @@ __global__ __launch_bounds__(512) void ffn_chain_kernel(FfnChainArgs a) {
   const long row = r0 + (long)wu * R + lr;
   const bool valid = lr < R && row < r1;
 
+  // A launch of several rounds of workgroups (one per CU at a time) would run in lockstep: all CUs load their rows
+  // together, compute together, store together, and the memory system idles through every compute phase (measured:
+  // the row phases then cost as much as the products).  The first workgroup of every CU therefore starts late by
+  // (its number / 8 mod 8) eighths of a workgroup's compute time; the rounds that follow inherit the spread, and a
+  // CU's row phases fall into the other CUs' compute phases.  The 100 MHz counter times the delay.
+  if (gridDim.x >= 512 && blockIdx.x < 256) {
+    const unsigned phase = (blockIdx.x >> 3) & 7;
+    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)phase * (48u * nchunks);
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+  }
+
   float* bias1_s = (float*)(smem + 2 * FC_STAGE);          // [F] (forward)
   float* vec_s = bias1_s + FC_MAXF;                        // [5][FC_VEC]: gamma, beta, bias2, gamma_next, beta_next
   {

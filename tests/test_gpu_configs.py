@@ -116,8 +116,8 @@ def test_s3_distillation_step_vs_oracle(S):
     l_dis = torch.nn.functional.mse_loss(student, latent)
     (l_atac + l_rna + 0.5 * l_dis).backward()
     for k, want in (("atac", l_atac), ("rna", l_rna), ("distill", l_dis)):
-        print(f"S3 loss {k}: {float(losses[k]):.6f} vs oracle {float(want):.6f}")
-        assert abs(float(losses[k]) - float(want)) <= 1e-3 * abs(float(want))
+        print(f"S3 loss {k}: {float(losses[k].detach()):.6f} vs oracle {float(want.detach()):.6f}")
+        assert abs(float(losses[k].detach()) - float(want.detach())) <= 1e-3 * abs(float(want.detach()))
     got = dict(m.named_parameters())
     worst = 0.0
     for k in names:
