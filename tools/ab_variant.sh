@@ -9,7 +9,9 @@ for i in 1 2; do
 import json, sys
 d = json.loads(open('/tmp/ab.json').readline())
 ks = d.get('kernels', {})
-names = [k for k in ks if 'favor' in k or 'ctx' in k or 'apply' in k]
+import os
+pat = os.environ.get('AB_KERNELS', 'favor').split(',')
+names = [k for k in ks if any(p_ in k for p_ in pat)]
 print('%-10s %.1f %s  ' % ('variant' if sys.argv[1] else 'product', d['value'], d['unit']),
       ' '.join('%s=%.3fms' % (k, ks[k]['ms_per_step']) for k in sorted(names)))
 PY
