@@ -4,7 +4,7 @@ usage (GPU box): python tools/kbench.py [filter]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scmomer_amd import ops
-T, D, H, F = 3 * 16906, 200, 10, 800
+T, D, H, F = int(os.environ.get("KB_CELLS", "3")) * 16906, 200, 10, 800
 INNER = 640
 dev = "cuda"
 bf, f32 = torch.bfloat16, torch.float32
