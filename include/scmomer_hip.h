@@ -56,7 +56,8 @@ typedef struct {
   void* dstT;
   int64_t ldt;
   int32_t chain; /* bit 0: dst columns, bit 1: dstT columns are written in the chain order of scm_ffn_chain_fwd */
-  int32_t reserved;
+  int32_t group_cells;               /* > 0: the batch is B / group_cells micro-batches stacked (B a multiple), one set
+                                      * of loss means per micro-batch; 0: one group */
 } scm_cast_item;
 int scm_cast_weights_batch(const scm_cast_item* items /* device */, int n, void* stream);
 /* FastAttention.projection_matrix f32 [266,64] (performer_pytorch.py:209) -> zero-padded bf16 [288,64]. */
@@ -337,12 +338,13 @@ int scm_cell_tail_fwd(const float* genes, const float* x, int B, int G, const sc
  *      reconstruct=True) (scmomer.py:41-94) with the student encoder of extract_cell_emb.py:27-40 and the linear
  *      decoders of utils.py:168-179.  The Performer, rna_projection and rna_ln are frozen (:233-246): `genes` is the
  *      encoder's per-gene output and gets no gradient.  f32 throughout.
- *      scm_distill_fwd: four launches -> losses[0..3] = {BCE, RNA MSE, distillation MSE, BCE + RNA MSE + distill_weight
- *        * distillation MSE} (means, as torch forms them; the last is the sum the script backpropagates, :295), and
- *        the tape the backward reads: the student's normalised hidden row, its dropped GELU output,
+ *      scm_distill_fwd: four launches -> per loss group g (see group_cells; one group by default) losses[4g .. 4g+3] =
+ *        {BCE, RNA MSE, distillation MSE, BCE + RNA MSE + distill_weight * distillation MSE} (means over the group's
+ *        cells, as torch forms them; the last is the sum the script backpropagates, :295), and the tape the backward reads: the student's normalised hidden row, its dropped GELU output,
  *        cat(student embedding, LayerNorm(normalised projection)), to_out's output, the LayerNorm's 1/std.
- *      scm_distill_bwd: four launches -> the gradients of gloss[0] BCE + gloss[1] MSE_rna + gloss[2] MSE_distill
- *        (gloss: three DEVICE floats) for the twelve trainable tensors, written (accumulate = 0) or added
+ *      scm_distill_bwd: four launches -> the gradients of the sum over the loss groups of gloss[0] BCE + gloss[1]
+ *        MSE_rna + gloss[2] MSE_distill (gloss: three DEVICE floats; the micro-batches of an accumulation window,
+ *        s3_pretrain_missing.py:296-299, in one call) for the twelve trainable tensors, written (accumulate = 0) or added
  *        (accumulate != 0: gradient accumulation, s3_pretrain_missing.py:296-299) to the given buffers.
  *      drop: the dropout layer's multipliers (0 or 1 / (1 - p)) per hidden unit [B, Hd], drawn by the caller; NULL =
  *        dropout off.  pos_weight: DEVICE, 1 value or one per peak.  B <= scm_distill_max_cells(); O must be 128.
@@ -353,7 +355,8 @@ typedef struct {
   int32_t B, G, Na;                  /* cells, genes (= RNA decoder rows), ATAC peaks (= ATAC decoder rows) */
   int32_t pos_weight_n;              /* 1 or Na */
   float distill_weight;              /* weight of the distillation term in losses[3] */
-  int32_t reserved;
+  int32_t group_cells;               /* > 0: the batch is B / group_cells micro-batches stacked (B a multiple), one set
+                                      * of loss means per micro-batch; 0: one group */
   const float* Wa; const float* ba;  /* ATAC.output_mean.0 [Na, O], [Na] */
   const float* Wr; const float* br;  /* RNA.output_mean.0 [G, O], [G] */
   const float* genes;                /* [B, G] the encoder's per-gene output */

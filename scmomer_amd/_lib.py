@@ -52,7 +52,7 @@ class CellTailArgs(C.Structure):
 class DistillArgs(C.Structure):
     """scm_distill_args"""
     _fields_ = [("tail", CellTailArgs), ("B", i32), ("G", i32), ("Na", i32), ("pos_weight_n", i32), ("distill_weight", C.c_float),
-                ("reserved", i32), ("Wa", vp), ("ba", vp),
+                ("group_cells", i32), ("Wa", vp), ("ba", vp),
                 ("Wr", vp), ("br", vp), ("genes", vp), ("x", vp), ("atac_raw", vp), ("latent", vp), ("drop", vp),
                 ("pos_weight", vp)]
 

@@ -562,6 +562,7 @@ static const char* distill_args_problem(const scm_distill_args* a) {
   if (w.O != 128) return "the decoders' input width (to_out's output) must be 128";
   if (a->B > distill_max_cells()) return "at most 32 cells per call";
   if (a->Na <= 0) return "need at least one ATAC peak";
+  if (a->group_cells < 0 || (a->group_cells > 0 && a->B % a->group_cells != 0)) return "group_cells must divide the number of cells";
   if ((int64_t)a->B * a->G >= (1ll << 31) || (int64_t)a->B * a->Na >= (1ll << 31)) return "operand too large";
   if (!(w.Wp && w.ln_p_w && w.ln_p_b && w.W1 && w.b1 && w.ln_h_w && w.ln_h_b && w.W2 && w.b2 && w.Wo && w.bo && a->Wa &&
         a->ba && a->Wr && a->br))

@@ -23,6 +23,9 @@ SCM_DEV float dt_gelu_grad(float v) {
   return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
 }
 
+// cells per loss group: the batch is group_cells-cell micro-batches stacked, each with its own loss means (0: one group)
+__host__ __device__ inline int distill_group_cells(const DistillArgs& a) { return a.group_cells > 0 ? a.group_cells : a.B; }
+
 constexpr int DT_O = 128;        // decoder input width (to_out: Linear(256, 128), scmomer.py:31): two floats per lane
 constexpr int DT_ROWS = 64;      // decoder rows per workgroup (4 waves x 16 rows)
 constexpr int DT_RPW = DT_ROWS / 4;
@@ -45,14 +48,14 @@ struct Tape {
     total = rstd + B;
   }
 };
-// scratch: [products partials | loss partials (2 per decoder workgroup) | d out partials (per decoder workgroup)
+// scratch: [products partials | loss partials (2 per decoder workgroup and loss group) | d out partials (per decoder workgroup)
 //           | per-cell vectors of the backward: d out [B,O], d a [B,P], d u [B,Hd], d h [B,Hd]]
 struct Scratch {
   long prod, loss, dout, v_dout, v_da, v_du, v_dh, total;
   int nwg;
   __host__ __device__ Scratch(int B, int G, int P, int Hd, int O, int Na) {
     nwg = (Na + G + DT_ROWS - 1) / DT_ROWS;
-    prod = 0; loss = prod + cell_tail_ws_floats(B, G, P, Hd); dout = loss + 2L * nwg;
+    prod = 0; loss = prod + cell_tail_ws_floats(B, G, P, Hd); dout = loss + 2L * nwg * B;   // room for one loss group per cell
     v_dout = dout + (long)nwg * B * O; v_da = v_dout + (long)B * O; v_du = v_da + (long)B * P;
     v_dh = v_du + (long)B * Hd; total = v_dh + (long)B * Hd;
   }
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(1024) void distill_mid_fwd_kernel(const float* __re
 // Row j of the stacked decoders: j < Na is peak j of ATAC.output_mean.0, else gene j - Na of RNA.output_mean.0.
 // A wave owns 16 consecutive rows; lane l holds columns 2l, 2l+1 of the row and of every cell's `out`; after the
 // wave sum lane b keeps cell b's logit and does that cell's loss term.
-// BWD = 0: loss partials (sum over the workgroup's rows and the cells) -> loss_partial[wg][2].
+// BWD = 0: loss partials (sum over the workgroup's rows and the cells of a loss group) -> loss_partial[wg][group][2].
 // BWD = 1: d z from the loss terms, the row's weight/bias gradient, and the workgroup's share of d out.
 template <int BMAX, int BWD>
 __global__ __launch_bounds__(256) void distill_decoder_kernel(DistillArgs a, const float* __restrict__ out,
@@ -134,8 +137,9 @@ __global__ __launch_bounds__(256) void distill_decoder_kernel(DistillArgs a, con
                                                               int accumulate, float* __restrict__ dout_partial) {
   __shared__ f32x2 ol[BMAX][64];
   __shared__ f32x2 dsum[BWD ? BMAX : 1][64];
-  __shared__ float red[4][2];
+  __shared__ float cellsum[4][32][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = a.B, Na = a.Na, G = a.G;
+  const int gc = distill_group_cells(a);
   for (int i = tid; i < BMAX * 64; i += 256) {
     const int b = i >> 6, l = i & 63;
     f32x2 v = {0.f, 0.f};
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(256) void distill_decoder_kernel(DistillArgs a, con
   float la = 0.f, lr = 0.f;
   float g_atac = 0.f, g_rna = 0.f;
   if (BWD) {
-    g_atac = gloss[0] / ((float)B * (float)Na);
-    g_rna = gloss[1] * 2.f / ((float)B * (float)G);
+    g_atac = gloss[0] / ((float)gc * (float)Na);
+    g_rna = gloss[1] * 2.f / ((float)gc * (float)G);
   }
   f32x2 dacc[BMAX];
 #pragma unroll
@@ -248,40 +252,46 @@ __global__ __launch_bounds__(256) void distill_decoder_kernel(DistillArgs a, con
       *(f32x2*)(dout_partial + ((long)blockIdx.x * B + b) * DT_O + 2 * l) = dsum[b][l];
     }
   } else {
-    la = wave_sum(la);
-    lr = wave_sum(lr);
-    if (lane == 0) { red[wave][0] = la; red[wave][1] = lr; }
+    // lane b holds cell b's sums over this wave's rows: per loss group, the cells and waves in a fixed order
+    if (lane < 32) { cellsum[wave][lane][0] = la; cellsum[wave][lane][1] = lr; }
     __syncthreads();
-    if (tid == 0) {
-      loss_partial[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-      loss_partial[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    const int ngroups = B / gc;
+    if (tid < 2 * ngroups) {
+      const int g = tid >> 1, which = tid & 1;
+      float s = 0.f;
+      for (int b = g * gc; b < (g + 1) * gc; ++b)
+        s += (cellsum[0][b][which] + cellsum[1][b][which]) + (cellsum[2][b][which] + cellsum[3][b][which]);
+      loss_partial[((long)blockIdx.x * ngroups + g) * 2 + which] = s;
     }
   }
 }
 
-// one workgroup of 256: losses[0..3] = L_atac, L_rna, L_dist, L_atac + L_rna + distill_weight L_dist
+// one workgroup of 256 per loss group: losses[group][0..3] = L_atac, L_rna, L_dist, L_atac + L_rna + distill_weight L_dist
 __global__ __launch_bounds__(256) void distill_loss_kernel(const float* __restrict__ loss_partial, int nwg,
                                                            DistillArgs a, const float* __restrict__ tape,
                                                            float* __restrict__ losses) {
   __shared__ float red[16];
-  const int tid = threadIdx.x, B = a.B, P = a.tail.P;
+  const int tid = threadIdx.x, B = a.B, P = a.tail.P, g = blockIdx.x, gc = distill_group_cells(a), ngroups = B / gc;
   const Tape tp(B, P, a.tail.Hd, a.tail.O);
   float la = 0.f, lr = 0.f, ld = 0.f;
-  for (int i = tid; i < nwg; i += 256) { la += loss_partial[2 * i]; lr += loss_partial[2 * i + 1]; }
-  for (int i = tid; i < B * P; i += 256) {
-    const int b = i / P, k = i % P;
-    const float d = tape[tp.cat + (long)b * 2 * P + k] - a.latent[i];
+  for (int i = tid; i < nwg; i += 256) {
+    la += loss_partial[((long)i * ngroups + g) * 2];
+    lr += loss_partial[((long)i * ngroups + g) * 2 + 1];
+  }
+  for (int i = tid; i < gc * P; i += 256) {
+    const int b = g * gc + i / P, k = i % P;
+    const float d = tape[tp.cat + (long)b * 2 * P + k] - a.latent[(long)b * P + k];
     ld += d * d;
   }
   la = dt_block_sum(la, red, 4);
   lr = dt_block_sum(lr, red, 4);
   ld = dt_block_sum(ld, red, 4);
   if (tid == 0) {
-    const float l0 = la / ((float)B * (float)a.Na), l1 = lr / ((float)B * (float)a.G), l2 = ld / ((float)B * (float)P);
-    losses[0] = l0;
-    losses[1] = l1;
-    losses[2] = l2;
-    losses[3] = (l0 + l1) + a.distill_weight * l2;
+    const float l0 = la / ((float)gc * (float)a.Na), l1 = lr / ((float)gc * (float)a.G), l2 = ld / ((float)gc * (float)P);
+    losses[4 * g] = l0;
+    losses[4 * g + 1] = l1;
+    losses[4 * g + 2] = l2;
+    losses[4 * g + 3] = (l0 + l1) + a.distill_weight * l2;
   }
 }
 
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(1024) void distill_mid_bwd_kernel(DistillArgs a, co
   if (tid < P) {
     float s = 0.f;
     for (int o = 0; o < O; ++o) s = fmaf(s_dout[o], w.Wo[(long)o * 2 * P + tid], s);
-    const float g_dist = gloss[2] * 2.f / ((float)B * (float)P);
+    const float g_dist = gloss[2] * 2.f / ((float)distill_group_cells(a) * (float)P);
     s += g_dist * (tape[tp.cat + (long)b * 2 * P + tid] - a.latent[(long)b * P + tid]);
     s_da[tid] = s;
     ws[off_da + (long)b * P + tid] = s;
@@ -443,7 +453,8 @@ hipError_t distill_fwd(const DistillArgs& a, float* tape, float* ws, float* loss
   threads = (threads + 63) / 64 * 64;
   hipLaunchKernelGGL(distill_mid_fwd_kernel, dim3(a.B), dim3(threads), 0, s, ws + sc.prod, nch, a, tape);
   launch_decoder<0>(a, tape + tp.out, ws + sc.loss, nullptr, DistillGrads{}, 0, nullptr, sc.nwg, s);
-  hipLaunchKernelGGL(distill_loss_kernel, dim3(1), dim3(256), 0, s, ws + sc.loss, sc.nwg, a, tape, losses);
+  hipLaunchKernelGGL(distill_loss_kernel, dim3(a.B / distill_group_cells(a)), dim3(256), 0, s, ws + sc.loss, sc.nwg, a, tape,
+                     losses);
   return hipGetLastError();
 }
 

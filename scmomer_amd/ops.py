@@ -571,6 +571,10 @@ def cell_tail(genes, x, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo, normalize: bool)
 DISTILL_GRAD_ORDER = ("W1", "b1", "ln_w", "ln_b", "W2", "b2", "Wo", "bo", "Wa", "ba", "Wr", "br")
 
 
+def distill_max_cells() -> int:
+    return int(lib.scm_distill_max_cells())
+
+
 def distill_supported(b: int, p: int, hd: int, o: int) -> bool:
     return cell_tail_supported(p, hd, o) and o == 128 and 0 < b <= lib.scm_distill_max_cells()
 
@@ -580,7 +584,7 @@ class DistillCall:
     points into, the tape and the scratch."""
 
     def __init__(self, genes, x, atac_raw, latent, drop, pos_weight, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo,
-                 wa, ba, wr, br, normalize: bool, distill_weight: float = 1.0):
+                 wa, ba, wr, br, normalize: bool, distill_weight: float = 1.0, group_cells: int = 0):
         tensors = [genes, x, atac_raw, latent, pos_weight, wp, *ln_p, w1, b1, *ln_h, w2, b2, wo, bo, wa, ba, wr, br]
         if drop is not None:
             tensors.append(drop)
@@ -601,6 +605,10 @@ class DistillCall:
         t.Wp, t.ln_p_w, t.ln_p_b, t.W1, t.b1 = _p(wp), _p(ln_p[0]), _p(ln_p[1]), _p(w1), _p(b1)
         t.ln_h_w, t.ln_h_b, t.W2, t.b2, t.Wo, t.bo = _p(ln_h[0]), _p(ln_h[1]), _p(w2), _p(b2), _p(wo), _p(bo)
         a.B, a.G, a.Na, a.pos_weight_n, a.distill_weight = b, g, na, pos_weight.numel(), float(distill_weight)
+        if group_cells and b % group_cells:
+            raise ValueError(f"distill tail: {b} cells do not split into groups of {group_cells}")
+        a.group_cells = int(group_cells or 0)
+        self.groups = b // group_cells if group_cells else 1
         a.Wa, a.ba, a.Wr, a.br = _p(wa), _p(ba), _p(wr), _p(br)
         a.genes, a.x, a.atac_raw, a.latent, a.drop, a.pos_weight = _p(genes), _p(x), _p(atac_raw), _p(latent), _p(drop), \
             _p(pos_weight)
@@ -614,8 +622,9 @@ class DistillCall:
         self.student = self.tape[2 * b * hd:2 * b * hd + b * 2 * p].view(b, 2 * p)[:, :p]   # the student's embedding
 
     def forward(self) -> torch.Tensor:
-        """-> losses [4] = (BCE, RNA MSE, distillation MSE, BCE + RNA MSE + distill_weight * distillation MSE)"""
-        losses = torch.empty(4, dtype=F32, device=self.tape.device)
+        """-> losses [groups, 4] = per loss group (BCE, RNA MSE, distillation MSE, BCE + RNA MSE + distill_weight *
+        distillation MSE)"""
+        losses = torch.empty((self.groups, 4), dtype=F32, device=self.tape.device)
         check(lib.scm_distill_fwd(C.byref(self.args), _p(self.tape), _p(self.ws), _p(losses), _stream()), "scm_distill_fwd")
         return losses
 

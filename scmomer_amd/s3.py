@@ -80,7 +80,8 @@ def encoder_scores(model, rna, group_cells=None):
             performer.stabiliser_group_cells = old
 
 
-def fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weight: float = 1.0, genes=None):
+def fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weight: float = 1.0, genes=None,
+                    group_cells: int = 0):
     """The kernel call for this batch (the frozen encoder runs here unless its per-gene output `genes` is given), or
     None when the kernels do not apply: another tail than the reference's, a frozen part that wants gradients, tensors that
     are not f32 on the GPU, more cells than one call takes."""
@@ -115,7 +116,7 @@ def fused_tail_call(model, rna, atac_raw, latent_real, pos_weight, distill_weigh
     return ops.DistillCall(genes, rna, atac_raw, latent_real, drop, pos_weight, d(model.rna_projection.weight),
                            (d(model.rna_ln.weight), d(model.rna_ln.bias)), d(w1), d(b1), (d(lw), d(lb)), d(w2), d(b2),
                            d(wo), d(bo), d(wa), d(ba), d(wr), d(br), normalize=bool(model.config.normalize),
-                           distill_weight=distill_weight)
+                           distill_weight=distill_weight, group_cells=group_cells)
 
 
 class _DistillTail(torch.autograd.Function):
@@ -124,7 +125,7 @@ class _DistillTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, call, *weights):
         ctx.call = call
-        return call.forward()
+        return call.forward()[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -202,23 +203,27 @@ class S3Step:
     def _forward_backward(self, rna, atac_raw, latent_real, groups: int = 1) -> torch.Tensor:
         """-> [groups, 4]: per micro-batch the losses in the order of LOSS_NAMES.  groups > 1 (tail kernels only): the
         inputs are that many micro-batches stacked; the frozen encoder runs once over all of them with one key
-        stabiliser per micro-batch, the tail once per micro-batch."""
+        stabiliser per micro-batch, the tail once with one set of loss means per micro-batch."""
         b = rna.shape[0] // groups
         if self._tail_accs is not None:
             if self._gloss is None:
                 self._gloss = torch.tensor([1.0, 1.0, float(self.distill_weight)], device=rna.device) / self.grad_acc
+            from . import ops
             genes = encoder_scores(self.model, rna, b if groups > 1 else None)
-            calls = [fused_tail_call(self.model, rna[g * b:(g + 1) * b], atac_raw[g * b:(g + 1) * b],
-                                     latent_real[g * b:(g + 1) * b], self.pos_weight, self.distill_weight,
-                                     genes=genes[g * b:(g + 1) * b]) for g in range(groups)]
-            if all(c is not None for c in calls):
-                out = []
-                for call in calls:
-                    out.append(call.forward())
-                    call.backward(self._gloss, grads=self._tail_accs, accumulate=True)
-                return torch.stack(out)
+            per_call = max(1, ops.distill_max_cells() // b)          # micro-batches one call of the tail takes
+            outs = []
+            for g0 in range(0, groups, per_call):
+                lo, hi = g0 * b, min(groups, g0 + per_call) * b
+                call = fused_tail_call(self.model, rna[lo:hi], atac_raw[lo:hi], latent_real[lo:hi], self.pos_weight,
+                                       self.distill_weight, genes=genes[lo:hi], group_cells=b if groups > 1 else 0)
+                if call is None:
+                    break
+                outs.append(call.forward())
+                call.backward(self._gloss, grads=self._tail_accs, accumulate=True)
+            else:
+                return outs[0] if len(outs) == 1 else torch.cat(outs)
             if groups > 1:
-                raise RuntimeError("S3 windows need the tail kernels (f32 GPU tensors, at most 32 cells per micro-batch)")
+                raise RuntimeError("S3 windows need the tail kernels (f32 GPU tensors, at most 32 cells per micro-batch)")   # nothing has been added to the accumulators: the first call already said no
             # the encoder has ticked its redraw counter for this call already: torch's tail on its output
             return self._torch_tail(genes, rna, atac_raw, latent_real).view(1, -1)
         if groups > 1:

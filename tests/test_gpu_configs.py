@@ -132,7 +132,7 @@ def test_s3_distillation_step_vs_oracle(S):
     # ---- the optimizer step of the driver: only the tail moves; the counter keeps ticking
     m.zero_grad(set_to_none=True)
     out_losses = step.micro_step(rna.to(DEV), atac_raw.to(DEV), latent.to(DEV))
-    assert abs(float(out_losses["total"]) - float(losses["total"])) <= 1e-6 * abs(float(losses["total"]))
+    assert abs(float(out_losses["total"]) - float(losses["total"].detach())) <= 1e-6 * abs(float(losses["total"].detach()))
     assert int(perf.calls_since_last_redraw) == 2
     after = dict(m.named_parameters())
     for k, v in before.items():
@@ -208,15 +208,18 @@ def test_cell_embedding_tail_kernel_equals_the_torch_tail(cells, genes, normaliz
         assert m._tail_operands(x) is None                  # gradients wanted: torch's tail
 
 
-@pytest.mark.parametrize("cells,genes,peaks,dropout,per_peak_weight",
-                         [(3, 16906, 20000, True, False), (5, 1000, 777, False, True), (17, 515, 130, True, False),
-                          (32, 333, 64, True, True), (1, 70, 3, False, False)])
-def test_distillation_tail_kernels_equal_the_torch_tail(cells, genes, peaks, dropout, per_peak_weight):
+@pytest.mark.parametrize("cells,genes,peaks,dropout,per_peak_weight,group_cells",
+                         [(3, 16906, 20000, True, False, 0), (5, 1000, 777, False, True, 0), (17, 515, 130, True, False, 0),
+                          (32, 333, 64, True, True, 0), (1, 70, 3, False, False, 0), (15, 16906, 2000, True, False, 3),
+                          (30, 400, 90, True, True, 3), (8, 300, 50, False, False, 4)])
+def test_distillation_tail_kernels_equal_the_torch_tail(cells, genes, peaks, dropout, per_peak_weight, group_cells):
     """The S3 tail (s3_pretrain_missing.py:291-307 after the frozen encoder: student MLP, to_out, the two linear
     decoders, BCE-with-logits with pos_weight + two MSE losses) and its backward as the eight launches of
     ops.DistillCall against the same layers and losses under torch autograd in f32, on random operands, with the
     same dropout multipliers.  Sums of up to 16,906 f32 terms in another order: losses to 2e-6 relative, every
-    gradient to 2e-5 of its largest entry; then the accumulating form adds the same gradients to what is there."""
+    gradient to 2e-5 of its largest entry; then the accumulating form adds the same gradients to what is there.
+    group_cells > 0: the batch is micro-batches of that many cells stacked -- one set of loss means per micro-batch,
+    the gradient of their sum (the accumulation window of :296-299 in one call)."""
     from scmomer_amd import ops
     torch.manual_seed(100 + cells)
     P, Hd, Ow = 128, 256, 128
@@ -243,18 +246,22 @@ def test_distillation_tail_kernels_equal_the_torch_tail(cells, genes, peaks, dro
         h = h * drop
     a = h @ tw2.t() + tb2
     out = torch.cat([a, rr], 1) @ two.t() + tbo
-    want = torch.stack([
-        torch.nn.functional.binary_cross_entropy_with_logits(out @ twa.t() + tba, (atac_raw > 0).float(),
+    gc = group_cells or cells
+    za, zr = out @ twa.t() + tba, out @ twr.t() + tbr
+    want = torch.stack([torch.stack([
+        torch.nn.functional.binary_cross_entropy_with_logits(za[g0:g0 + gc], (atac_raw[g0:g0 + gc] > 0).float(),
                                                              pos_weight=pos_weight),
-        torch.nn.functional.mse_loss(out @ twr.t() + tbr, x), torch.nn.functional.mse_loss(a, latent)])
+        torch.nn.functional.mse_loss(zr[g0:g0 + gc], x[g0:g0 + gc]),
+        torch.nn.functional.mse_loss(a[g0:g0 + gc], latent[g0:g0 + gc])]) for g0 in range(0, cells, gc)])
     (want * gloss).sum().backward()
 
     call = ops.DistillCall(gene_scores, x, atac_raw, latent, drop, pos_weight, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo,
-                           wa, ba, wr, br, normalize=True, distill_weight=0.3)
+                           wa, ba, wr, br, normalize=True, distill_weight=0.3, group_cells=group_cells)
     got = call.forward()
     want_d, a_d = want.detach(), a.detach()
-    assert float(((got[:3] - want_d).abs() / want_d.abs()).max()) <= 2e-6, (got, want_d)
-    assert abs(float(got[3]) - float(want_d[0] + want_d[1] + 0.3 * want_d[2])) <= 2e-6 * float(got[3])
+    assert tuple(got.shape) == (cells // gc, 4)
+    assert float(((got[:, :3] - want_d).abs() / want_d.abs()).max()) <= 2e-6, (got, want_d)
+    assert float((got[:, 3] - (want_d[:, 0] + want_d[:, 1] + 0.3 * want_d[:, 2])).abs().max()) <= 2e-6 * float(got[:, 3].max())
     assert float((call.student - a_d).abs().max()) <= 2e-5 * float(a_d.abs().max())
     grads = call.backward(gloss)
     worst = 0.0
@@ -265,7 +272,7 @@ def test_distillation_tail_kernels_equal_the_torch_tail(cells, genes, peaks, dro
     print(f"distillation tail, {cells} cells x {genes} genes x {peaks} peaks: worst gradient error {worst:.2e} of max")
     base = [torch.full_like(g, 0.25) for g in grads]
     call2 = ops.DistillCall(gene_scores, x, atac_raw, latent, drop, pos_weight, wp, ln_p, w1, b1, ln_h, w2, b2, wo, bo,
-                            wa, ba, wr, br, normalize=True)
+                            wa, ba, wr, br, normalize=True, group_cells=group_cells)
     call2.forward()
     call2.backward(gloss, grads=base, accumulate=True)
     for name, acc, g in zip(ops.DISTILL_GRAD_ORDER, base, grads):
@@ -275,8 +282,9 @@ def test_distillation_tail_kernels_equal_the_torch_tail(cells, genes, peaks, dro
 def test_s3_step_on_the_tail_kernels_follows_the_torch_tail(S, monkeypatch):
     """Two optimizer steps of two micro-steps with the tail on its kernels (forward, backward into the gradient
     accumulators, optimizer kernel) against the same steps with the tail and the optimizer on torch's library
-    code, dropout p = 0.1 with the same multipliers in both: same losses to 1e-5, weights within 2 % of the
-    distance they moved."""
+    code, dropout p = 0.1 with the same multipliers in both: same losses to 1e-5, weights within 5 % of the
+    distance they moved (Adam divides by the gradient's own magnitude: where a gradient entry is nearly zero, a
+    rounding difference moves the weight by a visible fraction of the learning rate)."""
     from scmomer_amd import s3
     n_peaks, bsz = 3000, 3
     p = O.make_scmomer_params(6)
@@ -317,15 +325,17 @@ def test_s3_step_on_the_tail_kernels_follows_the_torch_tail(S, monkeypatch):
             continue
         e = float((w0[k] - w1[k]).abs().max()) / moved
         worst = max(worst, e)
-        assert e <= 2e-2, f"{k}: {e:.3e}"
+        assert e <= 5e-2, f"{k}: {e:.3e}"
     print(f"S3 on the tail kernels vs torch tail after 2 optimizer steps: worst weight difference {worst:.2e} of the move")
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_s3_window_of_micro_steps_equals_the_micro_steps(S, monkeypatch, use_graph):
     """window_step over two stacked micro-batches (one launch chain: the frozen encoder once over six cells with a
-    key stabiliser per three, the tail kernels per micro-batch) == two micro_steps, bit for bit: losses per
-    micro-batch, the weights after two optimizer steps, and the redraw counter."""
+    key stabiliser per three, the tail kernels once with a set of loss means per micro-batch) against two micro_steps:
+    the losses per micro-batch of the first window bit for bit (same weights, same per-cell arithmetic), the later
+    ones and the weights after two optimizer steps to rounding (a window's gradients sum over its six cells in one
+    go), the redraw counter exactly."""
     from scmomer_amd import s3
     n_peaks, bsz = 1000, 3
     p = O.make_scmomer_params(6)
@@ -337,7 +347,8 @@ def test_s3_window_of_micro_steps_equals_the_micro_steps(S, monkeypatch, use_gra
                 torch.from_numpy((rng.random((bsz, n_peaks)) < 0.05).astype(np.float32)).to(DEV),
                 t(bsz, 128, sc=1.0).to(DEV)) for i in range(4)]
     keep = torch.nn.functional.dropout(torch.ones((bsz, 256), device=DEV), 0.1, True)
-    monkeypatch.setattr(torch.nn.functional, "dropout", lambda x, p=0.5, training=True, inplace=False: x * keep)
+    monkeypatch.setattr(torch.nn.functional, "dropout",
+                        lambda x, p=0.5, training=True, inplace=False: x * keep.repeat(x.shape[0] // bsz, 1))
     results = []
     for window in (1, 2):
         cfg = types.SimpleNamespace(projection_dim=128, normalize=True)
@@ -349,17 +360,24 @@ def test_s3_window_of_micro_steps_equals_the_micro_steps(S, monkeypatch, use_gra
         m.train()
         m.rna_model.model.performer.fix_projection_matrices_()
         step = s3.S3Step(m, lr=1e-3, grad_acc=2, pos_weight=2.0, distill_weight=0.5, use_graph=use_graph)
+        start = {k: v.detach().clone() for k, v in m.named_parameters()}
         if window == 1:
-            losses = torch.stack([step.micro_step(*b)["total"] for b in batches])
+            outs = [step.micro_step(*b) for b in batches]
+            losses = torch.stack([torch.stack([o[k] for k in s3.LOSS_NAMES]) for o in outs])
         else:
             stacked = [tuple(torch.cat([batches[i][j], batches[i + 1][j]]) for j in range(3)) for i in (0, 2)]
-            losses = torch.cat([step.window_step(*b, 2)["total"] for b in stacked])
+            outs = [step.window_step(*b, 2) for b in stacked]
+            losses = torch.cat([torch.stack([o[k] for k in s3.LOSS_NAMES], dim=1) for o in outs])
+        weights = {k: v.detach().clone() for k, v in m.named_parameters()}
+        if window == 2:
+            step.micro_step(*batches[0])
             with pytest.raises(ValueError):
-                step.micro_step(*batches[0]), step.window_step(*stacked[0], 2)      # would straddle the optimizer step
-        results.append((losses.clone(), {k: v.detach().clone() for k, v in m.named_parameters()},
-                        int(m.rna_model.model.performer.calls_since_last_redraw)))
-    (l0, w0, c0), (l1, w1, c1) = results
-    assert torch.equal(l0, l1), (l0, l1)
-    assert c0 == 4 and c1 == 5                      # the refused window never ran; the extra micro_step before it did
+                step.window_step(*stacked[0], 2)            # would straddle the optimizer step
+        results.append((losses.clone(), start, weights, int(m.rna_model.model.performer.calls_since_last_redraw)))
+    (l0, start, w0, c0), (l1, _, w1, c1) = results
+    assert torch.equal(l0[:2], l1[:2]), (l0, l1)
+    assert torch.allclose(l0[2:], l1[2:], rtol=1e-5, atol=0), (l0, l1)
+    assert c0 == 4 and c1 == 5                      # the refused window never ran; the micro_step before it did
     for k in w0:
-        assert torch.equal(w0[k], w1[k]), k
+        moved = float((w0[k] - start[k]).abs().max())
+        assert float((w0[k] - w1[k]).abs().max()) <= 1e-2 * moved, k     # Adam amplifies rounding where a gradient is tiny
