@@ -433,3 +433,17 @@ def test_trainer_uses_the_optimizer_kernel_and_keeps_torchs_state(mods):
             moved = float((sd_t[k] - fresh[k]).abs().max())
             assert moved > 0
             torch.testing.assert_close(sd_f[k], sd_t[k], rtol=0, atol=2e-5 * moved, msg=k)
+
+
+def test_rccl_calls_of_the_data_parallel_helpers_on_one_rank():
+    """The RCCL calls behind dist.py (gradient bucket all-reduce, parameter / projection / counter broadcasts, step-time
+    and flag reductions) on device tensors, in a child process with a one-rank process group (tests/rccl_single_rank.py):
+    a one-GPU box cannot hold two RCCL ranks, the multi-rank logic is covered by the gloo tests."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(here, "rccl_single_rank.py")], env=env, capture_output=True,
+                         text=True, timeout=150)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
