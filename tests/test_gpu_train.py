@@ -442,8 +442,12 @@ def test_rccl_calls_of_the_data_parallel_helpers_on_one_rank():
     import os
     import subprocess
     import sys
+    import socket
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sock:                       # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(here, "rccl_single_rank.py")], env=env, capture_output=True,
                          text=True, timeout=150)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
