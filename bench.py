@@ -410,7 +410,8 @@ def launch_ranks(args) -> int:
     """`python bench.py --gpus N` started directly (no torchrun): this process never touches the GPU runtime (it does
     not even count devices: a rank that finds no device of its own says so and exits non-zero), starts N copies
     of itself as ranks 0..N-1 (one per GPU, env:// rendezvous on 127.0.0.1, the layout torchrun would give them),
-    waits for all of them and relays rank 0's JSON line.  Returns the exit code."""
+    waits for all of them (stopping the others as soon as one fails) and relays rank 0's JSON line.  Returns the exit
+    code."""
     import socket
     import subprocess
     n = args.gpus
@@ -427,12 +428,36 @@ def launch_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    # Rank 0's output is read by a thread while this one watches all ranks: a rank that fails (no device of its own,
+    # a fault) must not leave the others waiting for it in a collective until somebody's time limit.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while True:
+        codes = [q.poll() for q in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            time.sleep(2.0)                                  # let the failing rank's message out, then stop the rest
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+            for q in procs:
+                try:
+                    q.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            codes = [q.wait() for q in procs]
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else ""
     if any(codes):
         sys.stdout.write(out0 or "")
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-        return next(c for c in codes if c) or 1
+        failed = [c for c in codes if c and c > 0]            # a rank's own failure, not the terminations it caused
+        return failed[0] if failed else 1
     line = None
     for ln in (out0 or "").splitlines():
         if ln.startswith("{"):
