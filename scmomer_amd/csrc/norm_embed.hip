@@ -250,19 +250,47 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
   f32x4 ag = f32x4{0, 0, 0, 0}, ab = ag;
   const float invD = 1.f / (float)D;
+  // what a row needs from memory, fetched one row ahead of its use (a wave walks about sixty rows one after the other:
+  // without this every row costs a full memory round trip)
+  struct RowIn { f32x4 v, d; float mu, rs; float dl[MAXC]; };
+  auto fetch = [&](long t) {
+    RowIn in;
+    in.v = in.d = f32x4{0, 0, 0, 0};
+    in.mu = in.rs = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) in.dl[c] = 0.f;
+    if (t < T) {
+      if (active) in.v = *(const f32x4*)(x + t * D + 4 * l);
+      in.mu = mean[t];
+      in.rs = rstd[t];
+      if (denc && active) in.d = *(const f32x4*)(denc + t * D + 4 * l);
+      if (dout) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          if (c < C) {
+            float dl = dout[t * C + c];
+            if (relu && !(out[t * C + c] > 0.f)) dl = 0.f;
+            in.dl[c] = dl;
+          }
+        }
+      }
+    }
+    return in;
+  };
+  RowIn next = fetch(wave);
   for (long t = wave; t < T; t += nwaves) {
-    f32x4 v = active ? *(const f32x4*)(x + t * D + 4 * l) : f32x4{0, 0, 0, 0};
-    const float mu = mean[t], rs = rstd[t];
-    f32x4 xh, y, d = f32x4{0, 0, 0, 0};
+    const RowIn in = next;
+    next = fetch(t + nwaves);
+    const f32x4 v = in.v;
+    const float mu = in.mu, rs = in.rs;
+    f32x4 xh, y, d = in.d;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { xh[j] = (v[j] - mu) * rs; y[j] = xh[j] * g[j] + b[j]; }
-    if (denc && active) d = *(const f32x4*)(denc + t * D + 4 * l);
     if (dout) {
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) {
         if (c < C) {
-          float dl = dout[t * C + c];
-          if (relu && !(out[t * C + c] > 0.f)) dl = 0.f;
+          const float dl = in.dl[c];
 #pragma unroll
           for (int j = 0; j < 4; ++j) { d[j] += dl * wv[c][j]; aw[c][j] += dl * y[j]; }
           abias[c] += dl;
