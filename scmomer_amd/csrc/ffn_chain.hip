@@ -71,7 +71,8 @@ __global__ __launch_bounds__(512) void ffn_chain_kernel(FfnChainArgs a) {
   if (gridDim.x >= 512 && blockIdx.x < 256) {
     const unsigned phase = (blockIdx.x >> 3) & 7;
     const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)phase * (48u * nchunks);
-    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+    // bounded: at most 512 naps of ~1 us, whatever the counter does
+    for (int nap = 0; nap < 512 && __builtin_amdgcn_s_memrealtime() < until; ++nap) __builtin_amdgcn_s_sleep(32);
   }
 
   float* bias1_s = (float*)(smem + 2 * FC_STAGE);          // [F] (forward)
