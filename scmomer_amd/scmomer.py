@@ -5,7 +5,9 @@ Same constructor, attribute names and ``state_dict`` keys as the reference, so i
 
 The encoder runs on the MI355X kernels.  The tail (two [B, 16906] x [16906, 128/256] products, normalisation, two
 LayerNorms, GELU, two narrow products) is two launches of its own kernel where no gradient is wanted and dropout is
-off (evaluation, extraction: ops.cell_tail); with gradients or in train mode it is torch library code.  The ATAC branch (a ViT) is not part of this path:
+off (evaluation, extraction: ops.cell_tail); the S3 distillation step runs it, its decoders, losses and backward
+on kernels of their own (s3.py, ops.DistillCall); any other use with gradients or in train mode goes through this
+module's forward, where the tail is torch library code.  The ATAC branch (a ViT) is not part of this path:
 ``atac_config`` must be None and mode='multimodal' raises.
 """
 import torch
